@@ -1,0 +1,1283 @@
+/*
+ * modes_oracle.c -- TEST INFRASTRUCTURE ONLY (see modes_oracle.h).
+ *
+ * A CPU restatement of the algorithm of gvanem/Dump1090's raw-IQ path, written from the
+ * reference's behaviour (not its text): table driven where the reference unrolls, closed
+ * form where the reference switches.  Every function cites the reference lines it follows
+ * ("ref:", relative to /root/reference/).
+ *
+ * PINNING STATUS
+ *   The reference is a Windows-only program (src/misc.h pulls winsock2.h/windows.h/shlwapi.h
+ *   into every translation unit of this path), so it cannot be compiled in this image from
+ *   its own files; no oracle/_ref build exists.  This restatement is pinned by
+ *     (1) the README's two messages decoded from testfiles/modes1.bin (README.md:289-305),
+ *     (2) the 219 magnitude->message vectors the reference's own demod_2000 debug dumper
+ *         left in tools/frames.js (phase correction + Manchester slicing + CRC),
+ *     (3) the CRC known answers and table sizes and the modes1.bin message/stat counts that
+ *         SURVEY.md (8c, App. B) recorded from the surveyor's run of the reference.
+ *   Not covered by any reference-held vector: the 112-bit slicing of demod_2400 beyond the
+ *   modes1.bin preamble counts, demod_8000 and demod_2400_AC ("parity unpinned" for those;
+ *   tests additionally check that frames injected by the synthetic generator come back).
+ *
+ * Floating point: x86-64 SSE2 semantics, no FMA contraction (build with -ffp-contract=off).
+ */
+#include "modes_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <stdbool.h>
+
+#define SHORT_BYTES 7
+#define LONG_BYTES  14
+#define SHORT_BITS  56
+#define LONG_BITS   112
+#define ICAO_CACHE_LEN 1024           /* ref: src/misc.h:664 */
+#define NON_ICAO (1u << 24)           /* ref: src/misc.h:699 */
+#define ASYNC_BUF_SIZE (256 * 1024)   /* ref: src/misc.h:649 */
+#define MAX_POWER (65535.0 * 65535.0) /* ref: src/misc.h:679-680 */
+
+/* ------------------------------------------------------------------------------------ */
+/* CRC (ref: src/crc.c)                                                                  */
+/* ------------------------------------------------------------------------------------ */
+
+typedef struct einfo {           /* ref: src/crc.h:13-17 */
+  uint32_t syndrome;
+  int      errors;
+  int8_t   bit[2];
+} einfo;
+
+static uint32_t g_crc_table[256];
+static uint32_t g_single_bit[LONG_BITS];
+static int      g_tables_ready;
+static uint16_t *g_mag_lut, *g_log10_lut;
+static const einfo NO_ERRORS = { 0, 0, { 0, 0 } };
+
+/* ref: src/crc.c:67-82 */
+uint32_t orc_crc_checksum (const uint8_t *msg, int bits)
+{
+  uint32_t rem = 0;
+  int n = bits / 8, i;
+  for (i = 0; i < n - 3; i++) {
+    rem = (rem << 8) ^ g_crc_table[msg[i] ^ ((rem & 0xFF0000) >> 16)];
+    rem &= 0xFFFFFF;
+  }
+  return rem ^ ((uint32_t)msg[n-3] << 16) ^ ((uint32_t)msg[n-2] << 8) ^ msg[n-1];
+}
+
+/* ref: src/crc.c:37-62 (poly 0xFFF409) and src/dump1090.c:385-423 (LUTs) */
+static void global_tables_init (void)
+{
+  int i, b;
+  uint8_t one[LONG_BYTES];
+  if (g_tables_ready) return;
+  for (i = 0; i < 256; i++) {
+    uint32_t c = (uint32_t)i << 16;
+    for (b = 0; b < 8; b++)
+      c = (c & 0x800000) ? ((c << 1) ^ 0xFFF409u) : (c << 1);
+    g_crc_table[i] = c & 0xFFFFFF;
+  }
+  memset (one, 0, sizeof one);
+  for (i = 0; i < LONG_BITS; i++) {
+    one[i >> 3] = (uint8_t)(1 << (7 - (i & 7)));
+    g_single_bit[i] = orc_crc_checksum (one, LONG_BITS);
+    one[i >> 3] = 0;
+  }
+  g_mag_lut = calloc (129 * 129, sizeof (uint16_t));
+  for (i = 0; i < 129; i++)
+    for (b = 0; b < 129; b++)
+      g_mag_lut[i * 129 + b] = (uint16_t) round (360 * hypot (i, b));
+  g_log10_lut = calloc (65536, sizeof (uint16_t));
+  for (i = 1; i < 65536; i++)
+    g_log10_lut[i] = (uint16_t) round (100.0 * log10 (i));
+  g_tables_ready = 1;
+}
+
+uint32_t orc_crc_table_entry (int i)     { global_tables_init (); return g_crc_table[i & 255]; }
+uint32_t orc_single_bit_syndrome (int i) { global_tables_init (); return g_single_bit[i]; }
+const uint16_t *orc_mag_lut (void)       { global_tables_init (); return g_mag_lut; }
+const uint16_t *orc_log10_lut (void)     { global_tables_init (); return g_log10_lut; }
+
+static int einfo_cmp (const void *x, const void *y)   /* ref: src/crc.c:87-93 */
+{
+  return (int)((const einfo *)x)->syndrome - (int)((const einfo *)y)->syndrome;
+}
+
+static int n_choose_k (int n, int k)                  /* ref: src/crc.c:98-114 */
+{
+  int r = 1, i;
+  if (k == 0 || k == n) return 1;
+  if (k > n) return 0;
+  for (i = 1; i <= k; i++) { r = r * n / i; n--; }
+  return r;
+}
+
+/* ref: src/crc.c:132-153 -- depth-first enumeration of error patterns */
+static int fill_patterns (einfo *t, int n, int offset, int first, int last,
+                          const einfo *base, int depth, int max_errors)
+{
+  int i;
+  if (depth >= max_errors) return n;
+  for (i = first; i < last; i++) {
+    t[n] = *base;
+    t[n].syndrome ^= g_single_bit[i + offset];
+    t[n].errors = depth + 1;
+    t[n].bit[depth] = (int8_t) i;
+    n++;
+    n = fill_patterns (t, n, offset, i + 1, last, &t[n-1], depth + 1, max_errors);
+  }
+  return n;
+}
+
+/* ref: src/crc.c:155-183 */
+static int mark_collisions (einfo *t, int tsize, int offset, int first, int last,
+                            uint32_t base_syn, int depth, int first_err, int last_err)
+{
+  int i, count = 0;
+  if (depth > last_err) return 0;
+  for (i = first; i < last; i++) {
+    einfo key;
+    key.syndrome = base_syn ^ g_single_bit[i + offset];
+    if (depth >= first_err) {
+      einfo *hit = bsearch (&key, t, tsize, sizeof (einfo), einfo_cmp);
+      if (hit && hit->errors != -1) { count++; hit->errors = -1; }
+    }
+    count += mark_collisions (t, tsize, offset, i + 1, last, key.syndrome, depth + 1, first_err, last_err);
+  }
+  return count;
+}
+
+/* ref: src/crc.c:189-270 */
+static einfo *build_error_table (int bits, int max_correct, int max_detect, int *size_out)
+{
+  int i, j, maxsize = 0, used;
+  einfo *t, base;
+  *size_out = 0;
+  if (!max_correct) return NULL;
+  for (i = 1; i <= max_correct; i++) maxsize += n_choose_k (bits - 5, i);
+  t = malloc ((maxsize + 1) * sizeof (einfo));
+  base.syndrome = 0; base.errors = 0; base.bit[0] = base.bit[1] = -1;
+  used = fill_patterns (t, 0, LONG_BITS - bits, 5, bits, &base, 0, max_correct);
+  qsort (t, used, sizeof (einfo), einfo_cmp);
+  /* the reference peeks at t[i+1] with i == used-1 (ref: src/crc.c:235); a sentinel that
+     can never match makes that read defined without changing the resulting table */
+  t[used].syndrome = 0xFFFFFFFFu;
+  for (i = 0, j = 0; i < used; i++) {
+    if (i < used - 1 && t[i+1].syndrome == t[i].syndrome) {
+      while (i < used && t[i+1].syndrome == t[i].syndrome) i++;
+      continue;                           /* all members of an ambiguous group are dropped */
+    }
+    if (i != j) t[j] = t[i];
+    j++;
+  }
+  if (j < used) used = j;
+  if (max_detect > max_correct) {
+    int flagged = mark_collisions (t, used, LONG_BITS - bits, 5, bits, 0, 1, max_correct + 1, max_detect);
+    if (flagged > 0) {
+      for (i = 0, j = 0; i < used; i++)
+        if (t[i].errors != -1) { if (i != j) t[j] = t[i]; j++; }
+      used = j;
+    }
+  }
+  *size_out = used;
+  return t;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* context                                                                               */
+/* ------------------------------------------------------------------------------------ */
+
+#define D8M_WIN_LEN    168
+#define D8M_LOOK_BACK  ((D8M_WIN_LEN + 4 + 1) * 8)     /* 1384, ref: src/demod-8000.c:50 */
+#define D8M_LOOK_AHEAD ((56 + 12) * 8)                 /* 544,  ref: src/demod-8000.c:56 */
+#define D8M_BUF_OVERLAP (D8M_LOOK_BACK + D8M_LOOK_AHEAD)
+#define D8M_SANE_MAX   50000000
+
+struct orc_ctx {
+  uint32_t sample_rate;
+  int fix_bits, phase_enhance, mode_ac, measure_noise;
+  einfo *short_tab, *long_tab;
+  int    short_sz, long_sz;
+  uint32_t icao[ICAO_CACHE_LEN];           /* addr per slot; TTL not modelled (constant time()) */
+  orc_stats st;
+  orc_msg *msgs; size_t nmsgs, capmsgs;
+  int cur_block;
+  /* demod_8000 file-static state (ref: src/demod-8000.c:80-89) */
+  int *d8_dbuf; size_t d8_dbuf_len;
+  int d8_acc, d8_bt_acc, d8_window, d8_win_start, d8_start_phase;
+  int d8_phase[8], d8_bt_phase[8];
+  int d8_match[D8M_WIN_LEN], d8_phase_ar[D8M_WIN_LEN];
+};
+
+orc_ctx *orc_create (uint32_t sample_rate, int fix_bits, int phase_enhance, int mode_ac, int measure_noise)
+{
+  orc_ctx *c = calloc (1, sizeof *c);
+  global_tables_init ();
+  c->sample_rate = sample_rate;
+  c->fix_bits = fix_bits; c->phase_enhance = phase_enhance; c->mode_ac = mode_ac; c->measure_noise = measure_noise;
+  /* ref: src/crc.c:281-307 */
+  if (fix_bits == 1) {
+    c->short_tab = build_error_table (SHORT_BITS, 1, 1, &c->short_sz);
+    c->long_tab  = build_error_table (LONG_BITS, 1, 1, &c->long_sz);
+  } else if (fix_bits != 0) {
+    c->short_tab = build_error_table (SHORT_BITS, 2, 4, &c->short_sz);
+    c->long_tab  = build_error_table (LONG_BITS, 2, 4, &c->long_sz);
+  }
+  /* ref: src/demod-8000.c:106-116; sized for the largest block this oracle is given */
+  c->d8_dbuf_len = D8M_BUF_OVERLAP + ASYNC_BUF_SIZE / 2;
+  c->d8_dbuf = calloc (c->d8_dbuf_len, sizeof (int));
+  return c;
+}
+
+void orc_destroy (orc_ctx *c)
+{
+  if (!c) return;
+  free (c->short_tab); free (c->long_tab); free (c->msgs); free (c->d8_dbuf); free (c);
+}
+
+void orc_reset (orc_ctx *c)
+{
+  memset (c->icao, 0, sizeof c->icao);
+  memset (&c->st, 0, sizeof c->st);
+  c->nmsgs = 0; c->cur_block = 0;
+  memset (c->d8_dbuf, 0, c->d8_dbuf_len * sizeof (int));
+  c->d8_acc = c->d8_bt_acc = c->d8_window = c->d8_win_start = c->d8_start_phase = 0;
+  memset (c->d8_phase, 0, sizeof c->d8_phase); memset (c->d8_bt_phase, 0, sizeof c->d8_bt_phase);
+  memset (c->d8_match, 0, sizeof c->d8_match); memset (c->d8_phase_ar, 0, sizeof c->d8_phase_ar);
+}
+
+int orc_error_table_size (const orc_ctx *c, int bits) { return bits == SHORT_BITS ? c->short_sz : c->long_sz; }
+
+uint32_t orc_error_table_entry (const orc_ctx *c, int bits, int k, int *errors, int *bit0, int *bit1)
+{
+  const einfo *t = bits == SHORT_BITS ? c->short_tab : c->long_tab;
+  *errors = t[k].errors; *bit0 = t[k].bit[0]; *bit1 = t[k].bit[1];
+  return t[k].syndrome;
+}
+
+/* ref: src/crc.c:314-339 */
+static const einfo *diagnose (const orc_ctx *c, uint32_t syndrome, int bits)
+{
+  const einfo *t; int n; einfo key;
+  if (syndrome == 0) return &NO_ERRORS;
+  if (bits == SHORT_BITS) { t = c->short_tab; n = c->short_sz; }
+  else                    { t = c->long_tab;  n = c->long_sz; }
+  if (!t) return NULL;
+  key.syndrome = syndrome;
+  return bsearch (&key, t, n, sizeof (einfo), einfo_cmp);
+}
+
+int orc_crc_diagnose (const orc_ctx *c, uint32_t syndrome, int bits, int *bit0, int *bit1)
+{
+  const einfo *e = diagnose (c, syndrome, bits);
+  if (!e) return -1;
+  *bit0 = e->bit[0]; *bit1 = e->bit[1];
+  return e->errors;
+}
+
+/* ref: src/crc.c:345-352 */
+static void apply_fix (uint8_t *msg, const einfo *e)
+{
+  int i;
+  for (i = 0; i < e->errors; i++)
+    msg[e->bit[i] >> 3] ^= (uint8_t)(1 << (7 - (e->bit[i] & 7)));
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* ICAO cache, score, accept (ref: src/dump1090.c)                                       */
+/* ------------------------------------------------------------------------------------ */
+
+static uint32_t icao_hash (uint32_t a)         /* ref: src/dump1090.c:1438-1447 */
+{
+  a = ((a >> 16) ^ a) * 0x45D9F3B;
+  a = ((a >> 16) ^ a) * 0x45D9F3B;
+  a = ((a >> 16) ^ a);
+  return a & (ICAO_CACHE_LEN - 1);
+}
+
+/* ref: src/dump1090.c:1455-1461; the `time(NULL)` stamp is a constant here */
+void orc_icao_add (orc_ctx *c, uint32_t addr) { c->icao[icao_hash (addr)] = addr; }
+
+/* ref: src/dump1090.c:1469-1476 */
+int orc_icao_test (const orc_ctx *c, uint32_t a)
+{
+  uint32_t s = c->icao[icao_hash (a)];
+  return s && s == a;
+}
+
+static int len_by_type (int df)                /* ref: src/dump1090.c:1427-1432 */
+{
+  return (df == 16 || df == 17 || df == 19 || df == 20 || df == 21) ? LONG_BITS : SHORT_BITS;
+}
+
+static uint32_t get_addr (const uint8_t *p)    /* ref: src/aircraft.c:2228-2231 */
+{
+  return ((uint32_t)p[0] << 16) | ((uint32_t)p[1] << 8) | p[2];
+}
+
+/* ref: src/dump1090.c:3225-3241 */
+static int fix_aa_field (uint32_t *addr, const einfo *e)
+{
+  int i, n = 0;
+  if (!e) return 0;
+  for (i = 0; i < e->errors; i++)
+    if (e->bit[i] >= 8 && e->bit[i] <= 31) { *addr ^= 1u << (31 - e->bit[i]); n++; }
+  return n;
+}
+
+/* ref: src/dump1090.c:3279-3365 */
+int orc_message_score (orc_ctx *c, const uint8_t *msg, int valid_bits)
+{
+  int df, bits, i, nz = 0, iid;
+  uint32_t crc, addr;
+  const einfo *e;
+
+  c->st.score_calls++;
+  if (valid_bits < 56) return -2;
+  df = msg[0] >> 3;
+  bits = len_by_type (df);
+  if (valid_bits < bits) return -2;
+  for (i = 0; i < bits / 8; i++) nz |= msg[i];
+  if (!nz) return -2;
+  crc = orc_crc_checksum (msg, bits);
+
+  switch (df) {
+    case 0: case 4: case 5: case 16: case 24:
+      return orc_icao_test (c, crc) ? 1000 : -1;
+    case 11:
+      iid = crc & 0x7F;
+      crc &= 0xFFFF80;
+      addr = get_addr (msg + 1);
+      e = diagnose (c, crc, bits);
+      if (!e || e->errors > 1) return -2;
+      fix_aa_field (&addr, e);
+      if (iid == 0)
+        return (orc_icao_test (c, addr) ? 1600 : 750) / (e->errors + 1);
+      return orc_icao_test (c, addr) ? 1000 / (e->errors + 1) : -1;
+    case 17: case 18:
+      e = diagnose (c, crc, bits);
+      if (!e) return -2;
+      addr = get_addr (msg + 1);
+      fix_aa_field (&addr, e);
+      return (orc_icao_test (c, addr) ? 1800 : 1400) / (e->errors + 1);
+    case 20: case 21:
+      return orc_icao_test (c, crc) ? 1000 : -2;
+    default:
+      return -2;
+  }
+}
+
+/* The only part of decode_extended_squitter that feeds back into the path: the
+ * MODES_NON_ICAO_ADDRESS bit of mm->addr (ref: src/dump1090.c:1900-2249). */
+static uint32_t es_non_icao (const uint8_t *msg, int df)
+{
+  int me_type = msg[4] >> 3;
+  int me_sub  = (me_type == 29) ? ((msg[4] & 6) >> 1) : (msg[4] & 7);
+  bool imf = false;
+  uint32_t flag = 0;
+
+  if (df == 18) {
+    switch (msg[0] & 7) {
+      case 0: break;
+      case 1: flag = NON_ICAO; break;
+      case 2: imf = true; break;
+      case 3: return (msg[4] & 0x80) ? NON_ICAO : 0;
+      case 5: flag = NON_ICAO; break;
+      case 6: imf = true; break;
+      default: return NON_ICAO;
+    }
+  }
+  if (!imf) return flag;
+  switch (me_type) {
+    case 19: if (msg[5] & 0x80) flag = NON_ICAO; break;
+    case 5: case 6: case 7: case 8: if (msg[6] & 0x08) flag = NON_ICAO; break;
+    case 0: case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16: case 17: case 18:
+    case 20: case 21: case 22: if (msg[4] & 0x01) flag = NON_ICAO; break;
+    case 28: if (me_sub == 1 && (msg[10] & 0x01)) flag = NON_ICAO; break;
+    case 31: if (msg[10] & 0x01) flag = NON_ICAO; break;
+    default: break;
+  }
+  return flag;
+}
+
+/* ref: src/dump1090.c:2372-2578 (CRC / accept part), 2586-2587 (AA), 2676-2687 (cache add),
+ *      2694-2720 (statistics wrapper) */
+static int decode_inner (orc_ctx *c, const uint8_t *in, orc_msg *mm)
+{
+  uint8_t *msg = mm->msg;
+  const einfo *e;
+  uint32_t a1, a2;
+  int iid = 0;
+
+  memcpy (msg, in, LONG_BYTES);
+  mm->msg_type = msg[0] >> 3;
+  mm->msg_bits = len_by_type (mm->msg_type);
+  mm->crc = orc_crc_checksum (msg, mm->msg_bits);
+  mm->error_bits = 0;
+  mm->addr = 0;
+  mm->sig_level = 0.0;
+  mm->score = 0;
+
+  switch (mm->msg_type) {
+    case 0: case 4: case 5: case 16:
+    case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31:
+      if (!orc_icao_test (c, mm->crc)) return -1;
+      mm->addr = mm->crc;
+      if (mm->msg_type >= 24) mm->msg_type = 24;
+      break;
+    case 11:
+      iid = mm->crc & 0x7F;
+      if (mm->crc & 0xFFFF80) {
+        e = diagnose (c, mm->crc & 0xFFFF80, mm->msg_bits);
+        if (!e || e->errors > 1) return -2;
+        mm->error_bits = e->errors;
+        apply_fix (msg, e);
+        if (!orc_icao_test (c, get_addr (msg + 1))) return -1;
+      }
+      break;
+    case 17: case 18:
+      if (mm->crc == 0) break;
+      e = diagnose (c, mm->crc, mm->msg_bits);
+      if (!e) return -2;
+      a1 = get_addr (msg + 1);
+      mm->error_bits = e->errors;
+      apply_fix (msg, e);
+      a2 = get_addr (msg + 1);
+      if (mm->error_bits == 2 && !orc_icao_test (c, a2)) return -1;
+      if (mm->error_bits == 1 && a1 != a2 && !orc_icao_test (c, a2)) return -1;
+      break;
+    case 20: case 21:
+      if (!orc_icao_test (c, mm->crc)) return -1;
+      mm->addr = mm->crc;
+      break;
+    default:
+      return -3;
+  }
+  if (mm->msg_type == 11 || mm->msg_type == 17 || mm->msg_type == 18)
+    mm->addr = get_addr (msg + 1);
+  if (mm->msg_type == 17 || mm->msg_type == 18)
+    mm->addr |= es_non_icao (msg, mm->msg_type);
+  if (!mm->error_bits && (mm->msg_type == 17 || mm->msg_type == 18 || (mm->msg_type == 11 && iid == 0)))
+    orc_icao_add (c, mm->addr);
+  return 0;
+}
+
+int orc_decode_message (orc_ctx *c, const uint8_t *msg, orc_msg *out)
+{
+  int rc = decode_inner (c, msg, out);
+  if (rc < 0) {
+    c->st.CRC_bad++;
+    if (rc == -1) c->st.demod_rejected_unknown++;
+  } else if (out->error_bits > 0) {
+    c->st.CRC_fixed++;
+    if (out->error_bits == 1) c->st.CRC_single_bit_fix++;
+    else if (out->error_bits == 2) c->st.CRC_two_bits_fix++;
+  } else
+    c->st.CRC_good++;
+  return rc;
+}
+
+/* modeS_user_message stand-in: record it */
+static void emit (orc_ctx *c, const orc_msg *mm)
+{
+  if (c->nmsgs == c->capmsgs) {
+    c->capmsgs = c->capmsgs ? c->capmsgs * 2 : 1024;
+    c->msgs = realloc (c->msgs, c->capmsgs * sizeof (orc_msg));
+  }
+  c->msgs[c->nmsgs++] = *mm;
+}
+
+static uint64_t ms_elapsed (uint64_t t1, uint64_t t2) { return (uint64_t)((int64_t)(t2 - t1) / 12000); }  /* ref: src/misc.c:1259-1262 */
+
+size_t         orc_num_messages (const orc_ctx *c) { return c->nmsgs; }
+const orc_msg *orc_messages (const orc_ctx *c)     { return c->msgs; }
+void           orc_get_stats (const orc_ctx *c, orc_stats *out) { *out = c->st; }
+size_t         orc_sizeof_msg (void) { return sizeof (orc_msg); }
+
+/* ------------------------------------------------------------------------------------ */
+/* converters (ref: src/convert.c)                                                       */
+/* ------------------------------------------------------------------------------------ */
+
+/* ref: src/convert.c:294-328 -- first row matching format and capabilities */
+int orc_convert_select (int format, int filter_dc, int compute_power)
+{
+  static const struct { int fmt, dc, pw; } rows[6] = {
+    { ORC_INPUT_UC8, 0, 0 }, { ORC_INPUT_UC8, 0, 1 }, { ORC_INPUT_UC8, 1, 1 },
+    { ORC_INPUT_SC16, 0, 0 }, { ORC_INPUT_SC16, 1, 1 }, { ORC_INPUT_SC16Q11, 1, 1 } };
+  int i;
+  for (i = 0; i < 6; i++) {
+    if (rows[i].fmt != format) continue;
+    if (filter_dc && !rows[i].dc) continue;
+    if (compute_power && !rows[i].pw) continue;
+    return i;
+  }
+  return -1;
+}
+
+/* ref: src/convert.c:346-362 */
+void orc_convert_state_init (orc_convert_state *st, double sample_rate, int filter_dc)
+{
+  st->z1_I = st->z1_Q = 0;
+  if (filter_dc) {
+    st->DC_B = exp (-2.0 * M_PI * 1.0 / sample_rate);
+    st->DC_A = 1.0 - st->DC_B;
+  } else {
+    st->DC_B = 1.0;
+    st->DC_A = 0.0;
+  }
+}
+
+/* ref: src/convert.c:13-110.  As written the table is indexed by ONE input byte, so output
+ * sample i depends on input byte i only and only nsamples bytes are consumed. */
+static void conv_uc8_lut (const uint8_t *in, uint16_t *out, unsigned n, int with_power, double *out_power)
+{
+  uint64_t power = 0;
+  unsigned i;
+  for (i = 0; i < n; i++) {
+    uint16_t mag = g_mag_lut[in[i]];
+    out[i] = mag;
+    power += (uint32_t)mag * (uint32_t)mag;
+  }
+  if (out_power) *out_power = with_power ? power / 65535.0 / 65535.0 : 0.0;
+}
+
+/* ref: src/convert.c:112-245 -- the three float converters differ only in the scaling of I/Q */
+static void conv_generic (int kind, const void *iq, uint16_t *out, unsigned n, orc_convert_state *st, double *out_power)
+{
+  const uint8_t *u8 = iq;
+  const uint16_t *u16 = iq;
+  float power = 0.0, z1_I = st->z1_I, z1_Q = st->z1_Q, A = st->DC_A, B = st->DC_B;
+  float fI, fQ, mag_sq;
+  unsigned i;
+  for (i = 0; i < n; i++) {
+    if (kind == ORC_CONV_UC8_GENERIC) {
+      uint8_t I = u8[2*i], Q = u8[2*i+1];
+      fI = (I - 127.5) / 127.5;
+      fQ = (Q - 127.5) / 127.5;
+    } else {
+      int16_t I = (int16_t) u16[2*i], Q = (int16_t) u16[2*i+1];
+      if (kind == ORC_CONV_SC16_GENERIC) { fI = I / 32768.0; fQ = Q / 32768.0; }
+      else                               { fI = I / 2048.0;  fQ = Q / 2048.0; }
+    }
+    z1_I = fI * A + z1_I * B;
+    z1_Q = fQ * A + z1_Q * B;
+    fI -= z1_I;
+    fQ -= z1_Q;
+    mag_sq = fI * fI + fQ * fQ;
+    if (mag_sq > 1) mag_sq = 1;
+    power += mag_sq;
+    out[i] = (uint16_t) (sqrtf (mag_sq) * 65535.0 + 0.5);
+  }
+  st->z1_I = z1_I; st->z1_Q = z1_Q;
+  if (out_power) *out_power = power;
+}
+
+/* ref: src/convert.c:247-292 -- octant-wise linear approximation of hypot */
+static void conv_sc16_int (const uint16_t *in, uint16_t *out, unsigned n, double *out_power)
+{
+  unsigned i;
+  for (i = 0; i < n; i++) {
+    uint32_t I = abs ((int16_t) in[2*i]), Q = abs ((int16_t) in[2*i+1]), mag;
+    if (I < Q)
+      mag = (I < ((106 * Q) >> 8)) ? (12868 * I + 64692 * Q) >> 16 : (36646 * I + 54842 * Q) >> 16;
+    else
+      mag = (I < ((618 * Q) >> 8)) ? (54842 * I + 36646 * Q) >> 16 : (64692 * I + 12868 * Q) >> 16;
+    out[i] = (uint16_t) mag;
+  }
+  if (out_power) *out_power = 0.0;
+}
+
+void orc_convert (int id, const void *iq, uint16_t *mag, unsigned n, orc_convert_state *st, double *out_power)
+{
+  global_tables_init ();
+  switch (id) {
+    case ORC_CONV_UC8_NODC_NOPOWER:  conv_uc8_lut (iq, mag, n, 0, out_power); break;
+    case ORC_CONV_UC8_NODC_POWER:    conv_uc8_lut (iq, mag, n, 1, out_power); break;
+    case ORC_CONV_SC16_NODC_NOPOWER: conv_sc16_int (iq, mag, n, out_power); break;
+    default:                         conv_generic (id, iq, mag, n, st, out_power); break;
+  }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* demod_2400 (ref: src/demod-2400.c)                                                    */
+/* ------------------------------------------------------------------------------------ */
+
+/* One Manchester bit at 2.4 MS/s covers 12/5 samples.  With `f` the offset of the bit start
+ * in fifths of a sample, the reference's slice_phase0..4 (ref: src/demod-2400.c:32-55) are
+ * the rows of this table applied at sample f/5 with row f%5. */
+static const int SLICE_W[5][4] = { {5,-3,-2,0}, {4,-1,-3,0}, {3,1,-4,0}, {2,3,-5,0}, {1,5,-5,-1} };
+static const int CORR_W[5] = { 26, 38, 38, 26, 19 };      /* ref: src/demod-2400.c:57-80 */
+
+static inline int slice_at (const uint16_t *m, int fifths)
+{
+  const int *w = SLICE_W[fifths % 5];
+  const uint16_t *p = m + fifths / 5;
+  int v = w[0] * p[0] + w[1] * p[1] + w[2] * p[2];
+  if (w[3]) v += w[3] * p[3];
+  return v;
+}
+
+/* ref: src/demod-2400.c:86-179.  correlate_check_N(&m[k]) is the weighted |slice| sum of the
+ * first five bits for start phase 5k+N; candidates 4..8, first strict maximum wins. */
+static int best_phase_2400 (const uint16_t *m)
+{
+  int best = -1, bestval = m[0] + m[1] + m[2] + m[3] + m[4] + m[5], t, k;
+  for (t = 4; t <= 8; t++) {
+    int v = 0;
+    for (k = 0; k < 5; k++) {
+      int f = t + 12 * k;
+      v += abs (slice_at (m, f) * CORR_W[f % 5]);
+    }
+    if (v > bestval) { bestval = v; best = t; }
+  }
+  return best;
+}
+
+/* ref: src/demod-2400.c:228-288 -- the five peak layouts; pairs are "p[a] > p[b]" */
+typedef struct { int8_t gt[6][2]; int8_t nhigh, high[6], nsig, sig[4], nnoise, noise[4]; } pre2400;
+static const pre2400 PRE2400[5] = {
+  { {{1,2},{3,2},{3,4},{9,8},{9,10},{11,10}},  5,{1,3,9,11,12,0},  3,{1,3,9,0},    3,{5,6,7,0} },
+  { {{1,2},{3,2},{3,4},{9,8},{9,10},{12,11}},  4,{1,3,9,12,0,0},   4,{1,3,9,12},   4,{5,6,7,8} },
+  { {{1,2},{3,2},{4,5},{9,8},{10,11},{12,11}}, 6,{1,3,4,9,10,12},  2,{1,12,0,0},   2,{6,7,0,0} },
+  { {{1,2},{4,3},{4,5},{10,9},{10,11},{12,11}},4,{1,4,10,12,0,0},  4,{1,4,10,12},  4,{5,6,7,8} },
+  { {{2,3},{4,3},{4,5},{10,9},{10,11},{12,11}},5,{1,2,4,10,12,0},  3,{4,10,12,0},  3,{6,7,8,0} } };
+
+void orc_demod_2400 (orc_ctx *c, const orc_mag_buf *mag)
+{
+  const uint16_t *m = mag->data;
+  uint32_t mlen = mag->valid_length - mag->overlap, j;
+  uint8_t bufs[2][LONG_BYTES];
+  uint64_t sum_scaled = 0;
+  int cur = 0;
+  orc_msg mm;
+
+  memset (&mm, 0, sizeof mm);
+  memset (bufs, 0, sizeof bufs);     /* the reference leaves these uninitialised */
+
+  for (j = 0; j < mlen; j++) {
+    const uint16_t *p = m + j;
+    int high = 0, k, t, first, last, bestscore = -2, bestphase = -1, msglen, rc;
+    uint32_t sig = 0, noise = 0;
+    const uint8_t *bestmsg = NULL;
+    const pre2400 *pat = NULL;
+
+    if (!(p[0] < p[1] && p[12] > p[13])) continue;        /* ref: :225 */
+    for (k = 0; k < 5 && !pat; k++) {
+      const pre2400 *q = &PRE2400[k];
+      int ok = 1, g;
+      for (g = 0; g < 6 && ok; g++) ok = p[q->gt[g][0]] > p[q->gt[g][1]];
+      if (ok) pat = q;
+    }
+    if (!pat) continue;
+    for (k = 0; k < pat->nhigh; k++)  high  += p[pat->high[k]];
+    for (k = 0; k < pat->nsig; k++)   sig   += p[pat->sig[k]];
+    for (k = 0; k < pat->nnoise; k++) noise += p[pat->noise[k]];
+    high /= 4;
+    if (sig * 2 < 3 * noise) continue;                    /* ref: :292 */
+    if (p[5] >= high || p[6] >= high || p[7] >= high || p[8] >= high || p[14] >= high ||
+        p[15] >= high || p[16] >= high || p[17] >= high || p[18] >= high) continue;   /* ref: :297-308 */
+
+    if (c->phase_enhance) { first = 4; last = 8; }
+    else {
+      first = last = best_phase_2400 (&p[19]);
+      if (first < 0) continue;
+    }
+    c->st.valid_preamble++;
+
+    for (t = first; t <= last; t++) {
+      uint8_t *msg = bufs[cur];
+      int nbytes = LONG_BYTES, i, score;
+      for (i = 0; i < nbytes; i++) {
+        uint8_t b = 0;
+        for (k = 0; k < 8; k++)
+          b = (uint8_t)((b << 1) | (slice_at (&m[j + 19], t + 12 * (8 * i + k)) > 0));
+        msg[i] = b;
+        if (i == 0) {                                     /* ref: :416-435 */
+          switch (b >> 3) {
+            case 0: case 4: case 5: case 11: nbytes = SHORT_BYTES; break;
+            case 16: case 17: case 18: case 20: case 21: case 24: break;
+            default: nbytes = 1; break;
+          }
+        }
+      }
+      score = orc_message_score (c, msg, i * 8);
+      if (score > bestscore) {
+        bestmsg = msg; bestscore = score; bestphase = t;
+        c->st.out_of_phase++;
+        cur ^= 1;
+      }
+    }
+    if (bestscore < 0) continue;
+
+    msglen = len_by_type (bestmsg[0] >> 3);
+    mm.timestamp = mag->sample_timestamp + (uint64_t)j * 5 + bestphase;    /* ref: :467 */
+    mm.sys_timestamp = mag->sys_timestamp + ms_elapsed (mag->sample_timestamp, mm.timestamp);
+    c->st.demodulated++;
+    rc = orc_decode_message (c, bestmsg, &mm);
+    if (rc < 0) continue;
+    mm.score = bestscore; mm.phase = bestphase; mm.block = c->cur_block; mm.j = (int32_t) j;
+    {                                                     /* ref: :486-505 */
+      uint64_t scaled = 0;
+      int slen = (msglen * 12) / 5;
+      double sp;
+      for (k = 0; k < slen; k++) { uint32_t v = m[j + 19 + k]; scaled += v * v; }
+      sp = scaled / 65535.0 / 65535.0;
+      mm.sig_level = sp / slen;
+      c->st.signal_power_sum += sp;
+      c->st.signal_power_count += slen;
+      sum_scaled += scaled;
+      if (mm.sig_level > c->st.peak_signal_power) c->st.peak_signal_power = mm.sig_level;
+      if (mm.sig_level > 0.50119) c->st.strong_signal_count++;
+    }
+    j += msglen * 12 / 5;                                 /* ref: :514 */
+    emit (c, &mm);
+  }
+  if (c->measure_noise) {                                 /* ref: :524-530 */
+    c->st.noise_power_sum += mag->mean_power - sum_scaled / 65535.0 / 65535.0;
+    c->st.noise_power_count += mag->total_length;
+  }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* demod_2000 (ref: src/demod-2000.c)                                                    */
+/* ------------------------------------------------------------------------------------ */
+
+/* ref: src/demod-2000.c:26-87.  Bit k of the Mode A reply ORs BIT into the code; "xx" slots
+ * set a high flag bit instead.  The gap table is the same list except slots 0, 14 and 17. */
+static const uint32_t MODEA_BIT[24] = {
+  0, 0x10, 0x1000, 0x20, 0x2000, 0x40, 0x4000, 0x40000000, 0x100, 0x1, 0x200, 0x2, 0x400, 0x4, 0,
+  0x08000000, 0x04000000, 0x80, 0x02000000, 0x01000000, 0x00800000, 0x00400000, 0x00200000, 0x00100000 };
+static uint32_t modea_gap (int k)
+{
+  return k == 0 ? 0x80000000u : k == 14 ? 0x20000000u : MODEA_BIT[k];
+}
+
+/* ref: src/demod-2000.c:123-321 */
+static int detect_mode_A (const uint16_t *m, orc_msg *mm)
+{
+  int m0 = m[0], m1 = m[1], m2, m3, n0, n1, n2, n3, phase, idx, j;
+  int f1s, f1n, f2s, f2n, fs, fn, level, lolo, code = 0, err = 0;
+  int sample, last_bit, last_space = 0, bit;
+  bool last_one;
+
+  if (m0 >= m1) return 0;
+  m2 = m[2]; m3 = m[3];
+  if (m2 <= m0 || m2 < m3) { m3 = m2; m2 = m0; }
+  if (m3 >= m1 || m0 > m2 || m3 > m2) return 0;
+  f1s = (m1 + m2) - ((m0 + m3) << 1);
+  f1n = (m0 + m3) >> 1;
+  if (f1s < 0x07FF || f1s < (f1n << 2)) return 0;
+
+  phase = (m2 * 20) / (m1 + m2);
+  idx = (phase + 812) / 20;
+  n0 = m[idx++]; n1 = m[idx++];
+  if (n0 >= n1) return 0;
+  n2 = m[idx++];
+  if ((phase + 812) % 20) n3 = m[idx++];
+  else { n3 = n2; n2 = n0; }
+  if (n3 >= n1 || n0 > n2 || n3 > n2) return 0;
+  f2s = (n1 + n2) - ((n0 + n3) << 1);
+  f2n = (n0 + n3) >> 1;
+  if (f2s < 0x07FF || f2s < (f2n << 2)) return 0;
+
+  fs = (f1s + f2s) >> 1;
+  fn = (f1n + f2n) >> 1;
+  lolo = fn + (fs >> 2);
+  level = fn + (fs >> 1);
+  last_one = true;
+  last_bit = f1s;
+
+  for (j = 1, phase += 29; j < 48; phase += 29, j++) {
+    idx = 1 + phase / 20;
+    sample = m[idx] - fn;
+    if (phase % 20) sample += m[idx + 1] - fn;
+    if (j & 1) { last_space = sample; continue; }
+    bit = j >> 1;
+    if (sample >= level) {
+      code |= MODEA_BIT[bit--];
+      if (last_one ? (last_space >= (sample >> 1) || last_space >= last_bit) : (last_space >= (sample >> 1)))
+        err |= modea_gap (bit);
+      last_one = true;
+    } else {
+      if (last_one ? (last_space >= last_bit) : (last_space >= lolo))
+        err |= modea_gap (bit);
+      last_one = false;
+    }
+    last_bit = sample >> 1;
+  }
+  if (code < 3 || (code & 0xFFFF8808) || err) return 0;
+  mm->sig_level = (fs + fn) * (fs + fn) / MAX_POWER;
+  return code;
+}
+
+/* ref: src/dump1090.c:2722-2766 */
+static void decode_mode_A (orc_msg *mm, int code)
+{
+  mm->msg_type = 32;
+  mm->msg_bits = 16;
+  mm->msg[0] = (uint8_t)(code >> 8);
+  mm->msg[1] = (uint8_t) code;
+  mm->addr = (code & 0x0000FF7F) | NON_ICAO;
+  mm->error_bits = 0;
+}
+
+static int out_of_phase_2000 (const uint16_t *p)      /* ref: src/demod-2000.c:479-503 */
+{
+  if (p[3] > p[2] / 3) return 1;
+  if (p[10] > p[9] / 3) return 1;
+  if (p[6] > p[7] / 3) return -1;
+  if (p[-1] > p[0] / 3) return -1;
+  return 0;
+}
+
+static uint16_t scale_clamped (uint16_t v, uint16_t scale)   /* ref: src/demod-2000.c:505-512 */
+{
+  uint32_t s = (uint32_t) v * scale / 16384;
+  return s > 65535 ? 65535 : (uint16_t) s;
+}
+
+/* ref: src/demod-2000.c:528-605; payload[0] is the first preamble sample */
+void orc_apply_phase_correction (uint16_t *pl)
+{
+  const int first = 16, end = 16 + 224;
+  uint32_t on_time = pl[0] + pl[2] + pl[7] + pl[9];
+  uint32_t early = (uint32_t)(pl[-1] + pl[6]) << 1;
+  uint32_t late  = (uint32_t)(pl[3] + pl[10]) << 1;
+  uint16_t up, down;
+  int j;
+
+  if (on_time == 0 && early == 0 && late == 0) return;
+  if (early > late) {
+    up   = (uint16_t)(16384 + 16384 * early / (early + on_time));
+    down = (uint16_t)(16384 - 16384 * early / (early + on_time));
+    pl[end - 1] = scale_clamped (pl[end - 1], up);
+    for (j = end - 2; j > first; j -= 2)
+      pl[j - 1] = scale_clamped (pl[j - 1], pl[j] > pl[j + 1] ? down : up);
+  } else {
+    up   = (uint16_t)(16384 + 16384 * late / (late + on_time));
+    down = (uint16_t)(16384 - 16384 * late / (late + on_time));
+    pl[first] = scale_clamped (pl[first], up);
+    for (j = first; j < end - 2; j += 2)
+      pl[j + 2] = scale_clamped (pl[j + 2], pl[j] > pl[j + 1] ? up : down);
+  }
+}
+
+/* The bit loop of demod_2000 (ref: src/demod-2000.c:768-937).  Returns msg_len (0/56/112). */
+typedef struct { int msg_len, errors; uint32_t sig, noise; int demodulated_inc; } slice2000;
+
+static slice2000 slice_2000 (const uint16_t *pre, const uint16_t *payload, uint8_t *msg)
+{
+  slice2000 r;
+  const uint16_t *ptr = payload;
+  uint8_t *out = msg, the_byte = 0, the_err = 0;
+  int errors = 0, errors56 = 0, errors_ty = 0, msg_len = LONG_BITS, scan_len = LONG_BITS, i;
+  uint32_t sig = pre[0] + pre[2] + pre[7] + pre[9];
+  uint32_t noise = pre[1] + pre[3] + pre[4] + pre[6] + pre[8];
+
+  r.demodulated_inc = 0;
+  for (i = 0; i < scan_len; i++) {
+    uint32_t a = *ptr++, b = *ptr++;
+    if (a > b) {
+      the_byte |= 1;
+      if (i < 56) { sig += a; noise += b; }
+    } else if (a < b) {
+      if (i < 56) { sig += b; noise += a; }
+    } else {
+      if (i < 56) { sig += a; noise += a; }
+      if (i >= SHORT_BITS)      errors++;
+      else if (i >= 5)          { scan_len = LONG_BITS; errors56 = ++errors; }
+      else if (i)               { errors_ty = errors56 = ++errors; the_err |= 1; }
+      else                      { errors_ty = errors56 = ++errors; the_err |= 1; the_byte |= 1; }
+    }
+    if ((i & 7) == 7)
+      *out++ = the_byte;
+    else if (i == 4) {
+      msg_len = len_by_type (the_byte);
+      if (errors == 0) { scan_len = msg_len; r.demodulated_inc++; }
+    }
+    the_byte = (uint8_t)(the_byte << 1);
+    if (i < 7) the_err = (uint8_t)(the_err << 1);
+
+    if (errors > 3) {                                   /* MODES_MSG_ENCODER_ERRS */
+      if (i < SHORT_BITS) msg_len = 0;
+      else if (errors_ty == 1 && the_err == 0x80) {
+        msg_len = SHORT_BITS; msg[0] ^= the_err; errors_ty = 0; errors = errors56;
+      } else if (i < LONG_BITS) { msg_len = SHORT_BITS; errors = errors56; }
+      else msg_len = LONG_BITS;
+      break;
+    }
+  }
+  if (msg_len > 0) {                                    /* ref: :894-901 */
+    i = len_by_type (msg[0] >> 3);
+    if (msg_len > i) msg_len = i;
+    else if (msg_len < i) msg_len = 0;
+  }
+  if (msg_len && errors_ty == 1 && (the_err & 0x78)) {  /* ref: :908-937 */
+    const uint32_t valid_df = 0x017F0831;
+    the_byte = msg[0];
+    if (!(valid_df & (1u << ((the_byte >> 3) & 0x1F)))) {
+      the_byte ^= the_err;
+      if (valid_df & (1u << ((the_byte >> 3) & 0x1F))) {
+        msg[0] = the_byte; errors--; r.demodulated_inc++;
+      }
+    }
+  }
+  r.msg_len = msg_len; r.errors = errors; r.sig = sig; r.noise = noise;
+  return r;
+}
+
+int orc_slice_2000 (const uint16_t *preamble, const uint16_t *payload, uint8_t *msg, int *errors_out)
+{
+  slice2000 r = slice_2000 (preamble, payload, msg);
+  if (errors_out) *errors_out = r.errors;
+  return r.msg_len;
+}
+
+void orc_demod_2000 (orc_ctx *c, const orc_mag_buf *mag)
+{
+  const uint16_t *m = mag->data;
+  uint32_t mlen = mag->valid_length - mag->overlap, j;
+  uint8_t msg[LONG_BYTES];
+  uint16_t aux[16 + 224 + 1];
+  bool use_correction = false;
+  orc_msg mm;
+
+  memset (&mm, 0, sizeof mm);
+  memset (msg, 0, sizeof msg);       /* uninitialised stack in the reference */
+
+  for (j = 0; j < mlen; j++) {
+    const uint16_t *pre = m + j, *payload = m + j + 16;
+    bool ok = false;
+    slice2000 s;
+    uint32_t sig, noise;
+    uint16_t snr;
+
+    mm.error_bits = 0;
+    if (!use_correction) {
+      int high;
+      if (c->mode_ac) {                                 /* ref: :677-701 */
+        int code = detect_mode_A (pre, &mm);
+        if (code) {
+          mm.timestamp = mag->sample_timestamp + ((uint64_t)(j + 1) * 6);
+          mm.sys_timestamp = mag->sys_timestamp + ms_elapsed (mag->sample_timestamp, mm.timestamp);
+          decode_mode_A (&mm, code);
+          mm.block = c->cur_block; mm.j = (int32_t) j; mm.score = -1; mm.phase = 0;
+          emit (c, &mm);
+          j += 50;                                      /* MODEAC_MSG_SAMPLES */
+          c->st.demod_modeac++;
+          continue;
+        }
+      }
+      if (!(pre[0] > pre[1] && pre[1] < pre[2] && pre[2] > pre[3] && pre[3] < pre[0] &&
+            pre[4] < pre[0] && pre[5] < pre[0] && pre[6] < pre[0] && pre[7] > pre[8] &&
+            pre[8] < pre[9] && pre[9] > pre[6]))
+        continue;                                       /* ref: :707-721 */
+      high = (pre[0] + pre[2] + pre[7] + pre[9]) / 6;
+      if (pre[4] >= high || pre[5] >= high) continue;
+      if (pre[11] >= high || pre[12] >= high || pre[13] >= high || pre[14] >= high) continue;
+      c->st.valid_preamble++;
+    } else {
+      memcpy (aux, &pre[-1], sizeof aux);               /* ref: :757-759 */
+      orc_apply_phase_correction (&aux[1]);
+      payload = &aux[1 + 16];
+    }
+
+    s = slice_2000 (pre, payload, msg);
+    c->st.demodulated += s.demodulated_inc;
+    sig = s.sig; noise = s.noise;
+    while (sig > 65535 || noise > 65535) { sig >>= 1; noise >>= 1; }     /* ref: :943-948 */
+    snr = (uint16_t)(g_log10_lut[sig] - g_log10_lut[noise]);
+
+    if (s.msg_len && (2 * snr) > (int)(4.0 * 10) && s.errors <= 3) {
+      int rc;
+      mm.timestamp = mag->sample_timestamp + (uint64_t) j * 6;          /* ref: :960 */
+      mm.sys_timestamp = mag->sys_timestamp + ms_elapsed (mag->sample_timestamp, mm.timestamp);
+      rc = orc_decode_message (c, msg, &mm);                            /* wipes the sig_level set at :966 */
+      ok = rc >= 0;
+      if (ok) {
+        mm.block = c->cur_block; mm.j = (int32_t) j; mm.score = -1; mm.phase = use_correction;
+        j += 2 * (8 + s.msg_len) - 1;                                   /* ref: :997 */
+        emit (c, &mm);
+      }
+    }
+    /* ref: :1016-1025; `pre` still points at the pre-skip position */
+    if (c->phase_enhance && (!ok || mm.error_bits > 0) && !use_correction && j && out_of_phase_2000 (pre)) {
+      use_correction = true;
+      c->st.out_of_phase++;
+      j--;
+    } else
+      use_correction = false;
+  }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* demod_2400_AC (ref: src/demod-2400AC.c)                                               */
+/* ------------------------------------------------------------------------------------ */
+
+void orc_demod_2400_AC (orc_ctx *c, const orc_mag_buf *mag)
+{
+  const uint16_t *m = mag->data;
+  uint32_t mlen = mag->valid_length - mag->overlap, f1;
+  double noise_stddev = sqrt (mag->mean_power - mag->mean_level * mag->mean_level);
+  unsigned noise_level = (unsigned) ((mag->mean_power + noise_stddev) * 65535 + 0.5);
+  orc_msg mm;
+  /* reply slot -> output bit (ref: :191-204); slots 0 and 14 are F1/F2 */
+  static const struct { unsigned in, out; } MAP[13] = {
+    {0x40000,0x0010},{0x20000,0x1000},{0x10000,0x0020},{0x08000,0x2000},{0x04000,0x0040},{0x02000,0x4000},
+    {0x00800,0x0100},{0x00400,0x0001},{0x00200,0x0200},{0x00100,0x0002},{0x00080,0x0400},{0x00040,0x0004},
+    {0x00004,0x0080} };
+
+  memset (&mm, 0, sizeof mm);
+  for (f1 = 1; f1 < mlen; f1++) {
+    unsigned f1_level, f2_level, top, f1_clock, f2_clock, f2, sig_thr, noise_thr;
+    unsigned bits = 0, noisy = 0, unsure = 0, bit, clock, code = 0, k;
+    float pa, pb, frac, mid;
+
+    if (!(m[f1-1] < m[f1])) continue;
+    if (m[f1+2] > m[f1] || m[f1+2] > m[f1+1]) continue;
+    f1_level = (m[f1] + m[f1+1]) / 2;
+    if (noise_level * 2 > f1_level) continue;
+
+    pa = (float) m[f1] * m[f1];
+    pb = (float) m[f1+1] * m[f1+1];
+    frac = pb / (pa + pb);
+    f1_clock = (unsigned) (25 * (f1 + frac * frac) + 0.5);
+    f2_clock = f1_clock + 87 * 14;
+    f2 = f2_clock / 25;
+    if (!(m[f2-1] < m[f2])) continue;
+    if (m[f2+2] > m[f2] || m[f2+2] > m[f2+1]) continue;
+    f2_level = (m[f2] + m[f2+1]) / 2;
+    if (noise_level * 2 > f2_level) continue;
+
+    top = f1_level > f2_level ? f1_level : f2_level;
+    mid = sqrtf (noise_level * top);
+    sig_thr   = (unsigned) (mid * M_SQRT2 + 0.5);
+    noise_thr = (unsigned) (mid / M_SQRT2 + 0.5);
+
+    for (bit = 0, clock = f1_clock; bit < 20; bit++, clock += 87) {
+      unsigned s = clock / 25;
+      bits <<= 1; noisy <<= 1; unsure <<= 1;
+      if (m[s+2] >= sig_thr) noisy |= 1;
+      if (m[s] >= sig_thr || m[s+1] >= sig_thr) bits |= 1;
+      else if (m[s] > noise_thr && m[s+1] > noise_thr) unsure |= 1;
+    }
+    if ((bits & 0x80020) != 0x80020) continue;
+    if (bits & 0x0101B) continue;
+    if (noisy || unsure) continue;
+    for (k = 0; k < 13; k++) if (bits & MAP[k].in) code |= MAP[k].out;
+
+    mm.timestamp = mag->sample_timestamp + f2_clock / 5;
+    mm.sys_timestamp = mag->sys_timestamp + ms_elapsed (mag->sample_timestamp, mm.timestamp);
+    c->st.valid_preamble++;
+    c->st.demod_modeac++;
+    decode_mode_A (&mm, (int) code);
+    mm.block = c->cur_block; mm.j = (int32_t) f1; mm.score = -1; mm.phase = 0;
+    emit (c, &mm);
+    f1 += 20 * 87 / 25;
+  }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* demod_8000 (ref: src/demod-8000.c)                                                    */
+/* ------------------------------------------------------------------------------------ */
+
+void orc_demod_8000 (orc_ctx *c, const orc_mag_buf *mag)
+{
+  const uint16_t *m = mag->data;
+  int mlen = (int)(mag->valid_length - mag->overlap);
+  int acc = c->d8_acc, bt_acc = c->d8_bt_acc, window = c->d8_window;
+  int win_start = c->d8_win_start, start_phase = c->d8_start_phase;
+  int phase[8], bt_phase[8], match[D8M_WIN_LEN], phase_ar[D8M_WIN_LEN];
+  int *dbuf, sptr, eptr, i, j, max, best;
+  uint8_t raw[LONG_BYTES + 2], best_msg[LONG_BYTES];
+  orc_msg mm;
+
+  memcpy (phase, c->d8_phase, sizeof phase);
+  memcpy (bt_phase, c->d8_bt_phase, sizeof bt_phase);
+  memcpy (match, c->d8_match, sizeof match);
+  memcpy (phase_ar, c->d8_phase_ar, sizeof phase_ar);
+  memset (&mm, 0, sizeof mm);
+  memset (best_msg, 0, sizeof best_msg);     /* uninitialised in the reference */
+
+  mlen &= ~7;
+  if ((size_t) mlen + D8M_BUF_OVERLAP > c->d8_dbuf_len) return;   /* oracle guard only */
+
+  /* 4-sample difference; the last 4 entries of a block stay raw (ref: :208-215) */
+  dbuf = c->d8_dbuf + D8M_BUF_OVERLAP;
+  for (j = 0; j < mlen; j++) {
+    dbuf[j] = m[j];
+    if ((size_t) j < (size_t) mlen - sizeof (*m) - 2) dbuf[j] -= m[j + 4];
+  }
+  dbuf = c->d8_dbuf + D8M_LOOK_BACK;
+  sptr = 0;
+  eptr = SHORT_BITS * 8;
+
+  while (sptr < mlen) {
+    int av;
+    max = 0;
+    for (i = 0; i < 8; i++) {                           /* ref: :235-271 */
+      phase[i] += abs (dbuf[eptr++]);
+      phase[i] -= abs (dbuf[sptr++]);
+      if (phase[i] > D8M_SANE_MAX || phase[i] < -D8M_SANE_MAX) {
+        int sum = 0, pos = eptr - 1, k;
+        for (k = 0; k < SHORT_BITS; k++, pos -= 8) sum += abs (dbuf[pos]);
+        phase[i] = sum;
+        c->st.d8m_drift_resets++;
+      }
+      if (phase[i] > max) max = phase[i];
+    }
+    acc += phase[0];                                    /* ref: :275-288 */
+    if (acc > D8M_SANE_MAX || acc < -D8M_SANE_MAX) { acc = 0; c->st.d8m_drift_resets++; }
+    av = acc >> 14;
+    acc -= av;
+
+    if (!(window || (max * 2 > av * 3))) continue;      /* ref: :302 */
+
+    max = best = 0;
+    for (i = 0; i < 8; i++) if (phase[i] > max) { best = i; max = phase[i]; }
+    if (window == 0) { win_start = sptr; start_phase = best; }
+    match[window] = phase[start_phase];
+    phase_ar[window] = best;
+    if (window == D8M_WIN_LEN - SHORT_BITS) { memcpy (bt_phase, phase, sizeof phase); bt_acc = acc; }
+    if (++window < D8M_WIN_LEN) continue;
+
+    {                                                   /* window complete (ref: :331-497) */
+      int best_result = -1, nbytes = SHORT_BYTES, pass, position, dptr;
+      int peak_short = 0, peak_long = 0, max0 = 0, max1 = 0;
+      window = 0;
+      for (i = 0; i < D8M_WIN_LEN - SHORT_BITS; i++) {  /* pick_peak, ref: :529-553 */
+        int both = match[i] + match[i + SHORT_BITS];
+        if (match[i] >= max0) { max0 = match[i]; peak_short = i; }
+        if (both >= max1)     { max1 = both;     peak_long = i; }
+      }
+      dptr = win_start + phase_ar[peak_short] + (peak_short - 4) * 8;
+      position = dptr;
+      for (pass = 0; pass < 2; pass++) {
+        for (i = 0; i < nbytes + 2; i++) {
+          uint8_t b = 0;
+          for (j = 0; j < 8; j++) {
+            int sum = dbuf[dptr-1] + dbuf[dptr] + dbuf[dptr+1];
+            b = (uint8_t)((b << 1) | ((sum >> 31) & 1));
+            dptr += 8;
+          }
+          raw[i] = (uint8_t) ~b;
+        }
+        for (i = 0; i < 16; i++) {                      /* D8M_SEARCH_WIDTH */
+          int r = orc_message_score (c, raw, nbytes * 8), k;
+          if (r > best_result) {
+            memcpy (best_msg, raw, nbytes);
+            best_result = r;
+            position = dptr - 64 + i * 8;
+          }
+          for (k = 0; k < nbytes + 2 - 1; k++) raw[k] = (uint8_t)((raw[k] << 1) | (raw[k+1] >> 7));
+          raw[k] = (uint8_t)(raw[k] << 1);
+        }
+        nbytes = LONG_BYTES;
+        dptr = win_start + phase_ar[peak_long] + (peak_long - 4) * 8;
+      }
+      if (best_result >= 0) {
+        int msglen = len_by_type (best_msg[0] >> 3), slen = msglen * 8, rc, m_start;
+        c->st.valid_preamble++;
+        mm.timestamp = mag->sample_timestamp +
+                       (uint64_t)(int64_t)((position - D8M_LOOK_AHEAD - slen - (int) mag->overlap) * 12 / 8);
+        mm.sys_timestamp = mag->sys_timestamp + ms_elapsed (mag->sample_timestamp, mm.timestamp);
+        c->st.demodulated++;
+        rc = orc_decode_message (c, best_msg, &mm);
+        if (rc >= 0) {
+          m_start = position - D8M_LOOK_AHEAD - slen;
+          if (m_start >= 0 && m_start + slen <= mlen) {
+            uint64_t scaled = 0;
+            int k;
+            for (k = 0; k < slen; k++) { uint32_t v = m[m_start + k]; scaled += v * v; }
+            mm.sig_level = (scaled / 65535.0 / 65535.0) / slen;
+          }
+        }
+        if (mm.addr && rc >= 0) {
+          mm.block = c->cur_block; mm.j = position; mm.score = best_result; mm.phase = 0;
+          emit (c, &mm);
+        }
+      }
+      sptr -= 55 * 8;                                   /* ref: :493-496 */
+      eptr -= 55 * 8;
+      memcpy (phase, bt_phase, sizeof phase);
+      acc = bt_acc;
+    }
+  }
+  memmove (c->d8_dbuf, c->d8_dbuf + mlen, D8M_BUF_OVERLAP * sizeof (int));
+  c->d8_acc = acc; c->d8_bt_acc = bt_acc; c->d8_window = window;
+  c->d8_win_start = win_start - mlen; c->d8_start_phase = start_phase;
+  memcpy (c->d8_phase, phase, sizeof phase);
+  memcpy (c->d8_bt_phase, bt_phase, sizeof bt_phase);
+  memcpy (c->d8_match, match, sizeof match);
+  memcpy (c->d8_phase_ar, phase_ar, sizeof phase_ar);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* bin_read + fifo geometry                                                              */
+/* ------------------------------------------------------------------------------------ */
+
+static uint32_t crc32_zlib (const uint8_t *p, size_t n)
+{
+  static uint32_t tab[256];
+  uint32_t c = 0xFFFFFFFFu;
+  size_t i;
+  if (!tab[1]) {
+    uint32_t k, b, v;
+    for (k = 0; k < 256; k++) { v = k; for (b = 0; b < 8; b++) v = (v & 1) ? 0xEDB88320u ^ (v >> 1) : v >> 1; tab[k] = v; }
+  }
+  for (i = 0; i < n; i++) c = tab[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+  return c ^ 0xFFFFFFFFu;
+}
+
+/* ref: src/infile.c:116-197 (one 256 KiB read per block, converter writes behind the overlap),
+ *      src/fifo.c:195-211 (previous tail copied in front; first block sees zeros),
+ *      src/dump1090.c:734 (trailing samples), src/infile.c:143 (block timestamp). */
+int orc_run_stream (orc_ctx *c, const void *iq, size_t nbytes, int format,
+                    int filter_dc, int compute_power, int which_demod, int also_ac,
+                    uint32_t *block_crc32, int max_blocks, double *block_power)
+{
+  const uint8_t *src = iq;
+  unsigned bps = (format == ORC_INPUT_UC8) ? 2 : 4;
+  uint32_t ov = (uint32_t)((8 + 112 + 16) * 1E-6 * c->sample_rate);
+  uint32_t bufsamples = ASYNC_BUF_SIZE / bps + ov;
+  uint16_t *data = calloc (bufsamples, sizeof (uint16_t));
+  uint16_t *tail = calloc (ov ? ov : 1, sizeof (uint16_t));
+  int conv = orc_convert_select (format, filter_dc, compute_power);
+  orc_convert_state st;
+  uint64_t counter = 0;
+  size_t off = 0;
+  int nblocks = 0, eof = 0;
+
+  if (conv < 0) { free (data); free (tail); return -1; }
+  orc_convert_state_init (&st, c->sample_rate, filter_dc);
+
+  while (!eof) {
+    size_t chunk = nbytes - off;
+    uint32_t nsamp;
+    orc_mag_buf mb;
+    if (chunk >= ASYNC_BUF_SIZE) chunk = ASYNC_BUF_SIZE; else eof = 1;   /* a short read ends the loop */
+    nsamp = (uint32_t)(chunk / bps);
+    memset (&mb, 0, sizeof mb);
+    mb.data = data; mb.total_length = bufsamples; mb.overlap = ov;
+    mb.sample_timestamp = (uint64_t)((counter * 12E6) / c->sample_rate);
+    orc_convert (conv, src + off, data + ov, nsamp, &st, &mb.mean_power);
+    mb.valid_length = ov + nsamp;
+    counter += nsamp;
+    off += chunk;
+    memcpy (data, tail, ov * sizeof (uint16_t));
+    memcpy (tail, data + mb.valid_length - ov, ov * sizeof (uint16_t));
+    if (block_crc32) block_crc32[nblocks] = crc32_zlib ((const uint8_t *)(data + ov), nsamp * sizeof (uint16_t));
+    if (block_power) block_power[nblocks] = mb.mean_power;
+    c->cur_block = nblocks;
+    switch (which_demod) {
+      case 2000: orc_demod_2000 (c, &mb); break;
+      case 2400: orc_demod_2400 (c, &mb); if (also_ac) orc_demod_2400_AC (c, &mb); break;
+      case 8000: orc_demod_8000 (c, &mb); break;
+      default: break;
+    }
+    nblocks++;
+    if (max_blocks > 0 && nblocks >= max_blocks) break;
+  }
+  free (data); free (tail);
+  return nblocks;
+}
