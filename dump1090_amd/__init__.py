@@ -1,0 +1,173 @@
+"""dump1090_amd -- host-side Python mirror of libmodes_hip.so (include/modes_hip.h).
+
+The library is the product: hand-written gfx950 kernels behind a C ABI that keeps the
+reference's convert.h / demod.h entry points.  This module only loads it (ctypes) and gives
+tests and bench.py the same calls with numpy / torch buffers.  There is no CPU fallback: if
+the shared library is missing the import fails.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmodes_hip.so")
+
+INPUT_ILLEGAL, INPUT_UC8, INPUT_SC16, INPUT_SC16Q11 = 0, 1, 2, 3
+MODES_OK = 0
+
+CONVERTER_NAMES = ["convert_uc8_nodc_nopower", "convert_uc8_nodc_power", "convert_uc8_generic",
+                   "convert_sc16_nodc_nopower", "convert_sc16_generic", "convert_sc16q11_generic"]
+
+MESSAGE_DTYPE = np.dtype([("timestamp", "<u8"), ("msg", "u1", (14,)), ("msg_bits", "u1"), ("msg_type", "u1"),
+                          ("addr", "<u4"), ("crc", "<u4"), ("score", "<i2"), ("error_bits", "u1"), ("phase", "u1"),
+                          ("block", "<u4"), ("sig_level", "<f8"), ("j", "<u4"), ("reserved", "<u4")])
+assert MESSAGE_DTYPE.itemsize == 56
+
+
+class EngineConfig(C.Structure):
+    _fields_ = [("sample_rate", C.c_uint32), ("input_format", C.c_int32), ("filter_dc", C.c_int32),
+                ("compute_power", C.c_int32), ("fix_bits", C.c_int32), ("phase_enhance", C.c_int32),
+                ("mode_ac", C.c_int32), ("device", C.c_int32), ("host_replay", C.c_int32),
+                ("reserved", C.c_int32 * 7)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("valid_preamble", "demodulated", "out_of_phase", "demod_modeac", "CRC_good", "CRC_bad", "CRC_fixed",
+                 "CRC_single_bit_fix", "CRC_two_bits_fix", "demod_rejected_unknown", "candidates", "replay_rounds")]
+
+    def asdict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class ConvertState(C.Structure):
+    _fields_ = [("DC_A", C.c_float), ("DC_B", C.c_float), ("z1_I", C.c_float), ("z1_Q", C.c_float),
+                ("func_name", C.c_char_p), ("description", C.c_char_p)]
+
+
+class MagBuf(C.Structure):
+    pass
+
+
+MagBuf._fields_ = [("data", C.POINTER(C.c_uint16)), ("total_length", C.c_uint), ("valid_length", C.c_uint),
+                   ("overlap", C.c_uint), ("sample_timestamp", C.c_uint64), ("sys_timestamp", C.c_uint64),
+                   ("flags", C.c_int), ("mean_level", C.c_double), ("mean_power", C.c_double),
+                   ("dropped", C.c_uint), ("next", C.POINTER(MagBuf))]
+
+CONVERT_FUNC = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint, C.POINTER(ConvertState), C.POINTER(C.c_double))
+
+
+class ModesError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libmodes_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ModesError("%s is missing: run `make -C dump1090_amd/csrc` (or __graft_entry__.build())" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.modes_last_error.restype = C.c_char_p
+        L.modes_engine_create.argtypes = [C.POINTER(EngineConfig), C.POINTER(C.c_void_p)]
+        L.modes_engine_destroy.argtypes = [C.c_void_p]
+        L.modes_engine_set_icao.argtypes = [C.c_void_p, C.c_void_p]
+        L.modes_engine_get_icao.argtypes = [C.c_void_p, C.c_void_p]
+        L.modes_engine_run_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.modes_engine_run_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64]
+        L.modes_engine_time_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
+                                             C.POINTER(C.c_float)]
+        L.modes_engine_num_messages.restype = C.c_size_t
+        L.modes_engine_num_messages.argtypes = [C.c_void_p]
+        L.modes_engine_messages.restype = C.c_void_p
+        L.modes_engine_messages.argtypes = [C.c_void_p]
+        L.modes_engine_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.modes_engine_tail_halo.restype = C.c_void_p
+        L.modes_engine_tail_halo.argtypes = [C.c_void_p]
+        L.modes_convert_device.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(ConvertState),
+                                           C.POINTER(C.c_double), C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != MODES_OK:
+        raise ModesError("modes_hip error %d: %s" % (rc, lib().modes_last_error().decode()))
+
+
+class Engine:
+    """Bulk engine (Part 3 of include/modes_hip.h)."""
+
+    def __init__(self, sample_rate=2400000, input_format=INPUT_UC8, filter_dc=False, compute_power=False, fix_bits=1,
+                 phase_enhance=False, mode_ac=False, device=0, host_replay=True):
+        self.L = lib()
+        cfg = EngineConfig(sample_rate=sample_rate, input_format=input_format, filter_dc=int(filter_dc),
+                           compute_power=int(compute_power), fix_bits=fix_bits, phase_enhance=int(phase_enhance),
+                           mode_ac=int(mode_ac), device=device, host_replay=int(host_replay))
+        h = C.c_void_p()
+        _check(self.L.modes_engine_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.modes_engine_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_icao(self, slots=None):
+        if slots is None:
+            _check(self.L.modes_engine_set_icao(self.h, None))
+        else:
+            a = np.ascontiguousarray(slots, dtype=np.uint32)
+            assert a.size == 1024
+            _check(self.L.modes_engine_set_icao(self.h, a.ctypes.data_as(C.c_void_p)))
+
+    def get_icao(self):
+        a = np.zeros(1024, dtype=np.uint32)
+        _check(self.L.modes_engine_get_icao(self.h, a.ctypes.data_as(C.c_void_p)))
+        return a
+
+    def run_device(self, data_ptr, nbytes, first_sample=0, halo_ptr=None, stream=None):
+        """data_ptr: device address (e.g. torch_tensor.data_ptr())."""
+        _check(self.L.modes_engine_run_device(self.h, C.c_void_p(data_ptr), nbytes, first_sample,
+                                              C.c_void_p(halo_ptr) if halo_ptr else None,
+                                              C.c_void_p(stream) if stream else None))
+
+    def run_host(self, iq, first_sample=0):
+        iq = np.ascontiguousarray(iq)
+        _check(self.L.modes_engine_run_host(self.h, iq.ctypes.data_as(C.c_void_p), iq.nbytes, first_sample))
+
+    def time_scan(self, data_ptr, nbytes, reps=10, stream=None):
+        ms = C.c_float()
+        _check(self.L.modes_engine_time_scan(self.h, C.c_void_p(data_ptr), nbytes, reps,
+                                             C.c_void_p(stream) if stream else None, C.byref(ms)))
+        return ms.value
+
+    def messages(self):
+        n = self.L.modes_engine_num_messages(self.h)
+        if n == 0:
+            return np.zeros(0, dtype=MESSAGE_DTYPE)
+        buf = (C.c_char * (n * MESSAGE_DTYPE.itemsize)).from_address(self.L.modes_engine_messages(self.h))
+        return np.frombuffer(buf, dtype=MESSAGE_DTYPE).copy()
+
+    def stats(self):
+        s = Stats()
+        _check(self.L.modes_engine_get_stats(self.h, C.byref(s)))
+        return s.asdict()
+
+
+def convert_device(conv_id, d_iq_ptr, d_mag_ptr, nsamples, state=None, want_power=True, stream=None):
+    p = C.c_double(-1.0)
+    _check(lib().modes_convert_device(conv_id, C.c_void_p(d_iq_ptr), C.c_void_p(d_mag_ptr), nsamples,
+                                      C.byref(state) if state is not None else None,
+                                      C.byref(p) if want_power else None, C.c_void_p(stream) if stream else None))
+    return p.value
+
+
+def msg_hex(rec):
+    return bytes(rec["msg"][: int(rec["msg_bits"]) // 8]).hex()

@@ -1,0 +1,167 @@
+#include "accept.h"
+
+#include <algorithm>
+#include <cstring>
+
+namespace modes {
+
+void IcaoCache::clear () { memset (slot_, 0, sizeof slot_); }
+
+uint32_t IcaoCache::hash (uint32_t a)
+{
+  a = ((a >> 16) ^ a) * 0x45D9F3Bu;
+  a = ((a >> 16) ^ a) * 0x45D9F3Bu;
+  a = (a >> 16) ^ a;
+  return a & (kIcaoSlots - 1);
+}
+
+static inline uint32_t aa_field (const uint8_t *msg) { return (uint32_t (msg[1]) << 16) | (uint32_t (msg[2]) << 8) | msg[3]; }
+
+// AA as it would read after the table's repair (ref: src/dump1090.c:3225-3241): only flips that land in bits 8..31
+static inline uint32_t aa_after_repair (const Record &r)
+{
+  uint32_t a = aa_field (r.msg);
+  const int8_t b[2] = { r.bit0, r.bit1 };
+  for (int i = 0; i < r.nerr; i++)
+    if (b[i] >= 8 && b[i] <= 31) a ^= 1u << (31 - b[i]);
+  return a;
+}
+
+int score_record (const Record &r, const IcaoCache &cache)
+{
+  switch (r.cls) {
+    case kClsAP:  return cache.test (r.crc) ? 1000 : -1;
+    case kClsAP2: return cache.test (r.crc) ? 1000 : -2;
+    case kClsDF11: {
+      const bool known = cache.test (aa_after_repair (r));
+      if ((r.crc & 0x7F) == 0) return (known ? 1600 : 750) / (r.nerr + 1);
+      return known ? 1000 / (r.nerr + 1) : -1;
+    }
+    default:
+      return (cache.test (aa_after_repair (r)) ? 1800 : 1400) / (r.nerr + 1);
+  }
+}
+
+// Which extended squitters carry a non-ICAO address (the only output of decode_extended_squitter
+// that reaches mm->addr; ref: src/dump1090.c:1918-1963, 1990, 2097, 2130, 2220, 2239).
+static uint32_t non_icao_flag (const uint8_t *msg, int df)
+{
+  bool look_for_imf = false;
+  if (df == 18) {
+    const int cf = msg[0] & 7;
+    if (cf == 1 || cf == 5) return kNonIcao;
+    if (cf == 3) return (msg[4] & 0x80) ? kNonIcao : 0;
+    if (cf == 4 || cf == 7) return kNonIcao;
+    look_for_imf = (cf == 2 || cf == 6);
+  }
+  if (!look_for_imf) return 0;
+  const int type = msg[4] >> 3;
+  bool imf = false;
+  if (type == 19) imf = msg[5] & 0x80;
+  else if (type >= 5 && type <= 8) imf = msg[6] & 0x08;
+  else if (type == 0 || (type >= 9 && type <= 18) || (type >= 20 && type <= 22)) imf = msg[4] & 0x01;
+  else if (type == 28) imf = (msg[4] & 7) == 1 && (msg[10] & 0x01);
+  else if (type == 31) imf = msg[10] & 0x01;
+  return imf ? kNonIcao : 0;
+}
+
+static inline void flip (uint8_t *msg, int bit) { msg[bit >> 3] ^= uint8_t (0x80u >> (bit & 7)); }
+
+int accept_record (const Record &r, IcaoCache &cache, modes_message *out)
+{
+  uint8_t *msg = out->msg;
+  memcpy (msg, r.msg, kLongBytes);
+  out->msg_type = r.df;
+  out->msg_bits = uint8_t (len_by_type (r.df));
+  out->crc = r.crc;
+  out->error_bits = 0;
+  out->addr = 0;
+  out->sig_level = 0.0;
+
+  bool clean_announcer = false;
+  switch (r.cls) {
+    case kClsAP:
+    case kClsAP2:
+      if (!cache.test (r.crc)) return -1;
+      out->addr = r.crc;
+      if (r.df >= 24) out->msg_type = 24;
+      return 0;
+    case kClsDF11:
+      if (r.crc & 0xFFFF80u) {
+        out->error_bits = uint8_t (r.nerr);
+        if (r.nerr >= 1) flip (msg, r.bit0);
+        if (!cache.test (aa_field (msg))) return -1;
+      }
+      out->addr = aa_field (msg);
+      clean_announcer = out->error_bits == 0 && (r.crc & 0x7F) == 0;
+      break;
+    default: {
+      if (r.crc != 0) {
+        const uint32_t before = aa_field (msg);
+        out->error_bits = uint8_t (r.nerr);
+        if (r.nerr >= 1) flip (msg, r.bit0);
+        if (r.nerr >= 2) flip (msg, r.bit1);
+        const uint32_t after = aa_field (msg);
+        if (r.nerr == 2 && !cache.test (after)) return -1;
+        if (r.nerr == 1 && before != after && !cache.test (after)) return -1;
+      }
+      out->addr = aa_field (msg) | non_icao_flag (msg, r.df);
+      clean_announcer = out->error_bits == 0;
+      break;
+    }
+  }
+  if (clean_announcer) cache.add (out->addr);
+  return 0;
+}
+
+void accept_pass_2400 (const Record *rec, const uint64_t *pos, size_t n, uint32_t B, uint64_t first_sample,
+                       uint32_t sample_rate, IcaoCache &cache, AcceptStats &st,
+                       std::vector<modes_message> &out, std::vector<uint64_t> &out_pos,
+                       const uint64_t *vp_bitmap, uint64_t nsamples)
+{
+  uint64_t cur_block = ~0ull, skip_until = 0;
+  for (size_t i = 0; i < n;) {
+    size_t g = i + 1;
+    while (g < n && pos[g] == pos[i]) g++;          // same offset, other phases (phase_enhance)
+    const uint64_t blk = pos[i] / B, j = pos[i] % B;
+    if (blk != cur_block) { cur_block = blk; skip_until = 0; }   // each demod_2400 call starts at j = 0
+    if (j < skip_until) { i = g; continue; }
+
+    int best = -2; size_t besti = i;
+    for (size_t k = i; k < g; k++) {
+      const int s = score_record (rec[k], cache);
+      if (s > best) { best = s; besti = k; st.out_of_phase++; }
+    }
+    i = g;
+    if (best < 0) continue;
+
+    st.demodulated++;
+    modes_message mm;
+    memset (&mm, 0, sizeof mm);
+    const Record &r = rec[besti];
+    const int rc = accept_record (r, cache, &mm);
+    if (rc < 0) { st.CRC_bad++; if (rc == -1) st.rejected_unknown++; continue; }
+    if (mm.error_bits) {
+      st.CRC_fixed++;
+      if (mm.error_bits == 1) st.CRC_single_bit_fix++; else st.CRC_two_bits_fix++;
+    } else st.CRC_good++;
+
+    const uint64_t counter = first_sample + blk * B;
+    const uint64_t block_ts = uint64_t ((double (counter) * 12E6) / double (sample_rate));   // ref: src/infile.c:143
+    mm.timestamp = block_ts + j * 5 + r.phase;                                                // ref: src/demod-2400.c:467
+    mm.score = int16_t (best);
+    mm.phase = r.phase;
+    mm.block = uint32_t (first_sample / B + blk);
+    mm.j = uint32_t (j);
+    out.push_back (mm);
+    out_pos.push_back (pos[besti]);
+    skip_until = j + uint64_t (len_by_type (r.df)) * 12 / 5 + 1;                              // ref: src/demod-2400.c:514
+    if (vp_bitmap) {
+      // positions (j, skip_until) of this block are never examined by the reference's loop
+      uint64_t a = blk * B + j + 1, b = std::min (blk * B + std::min<uint64_t> (skip_until, B), nsamples);
+      for (uint64_t q = a; q < b; q++) st.skipped_preambles += (vp_bitmap[q >> 6] >> (q & 63)) & 1;
+    }
+  }
+}
+
+}  // namespace modes

@@ -1,0 +1,51 @@
+// The ordered accept pass on the host: what the reference does, in order, with every candidate
+// that reached modeS_message_score() -- ICAO cache tests and updates, score comparison,
+// decode_mode_S_message()'s CRC/repair/accept rules, skip-ahead -- applied to the records the
+// scan kernel left.  Works on pre-digested records (syndrome + table hit already known).
+#pragma once
+#include <stdint.h>
+#include <vector>
+#include "common.h"
+#include "../../include/modes_hip.h"
+
+namespace modes {
+
+// ref: src/dump1090.c:1438-1476.  One address per slot; the reference's TTL compares wall-clock
+// seconds (60 s), which a file run never reaches at these speeds: not modelled.
+class IcaoCache {
+ public:
+  IcaoCache () { clear (); }
+  void clear ();
+  static uint32_t hash (uint32_t a);
+  void add (uint32_t a) { slot_[hash (a)] = a; }
+  bool test (uint32_t a) const { uint32_t s = slot_[hash (a)]; return s && s == a; }
+  uint32_t *raw () { return slot_; }
+  const uint32_t *raw () const { return slot_; }
+ private:
+  uint32_t slot_[kIcaoSlots];
+};
+
+struct AcceptStats {
+  uint64_t demodulated = 0, out_of_phase = 0, CRC_good = 0, CRC_bad = 0, CRC_fixed = 0,
+           CRC_single_bit_fix = 0, CRC_two_bits_fix = 0, rejected_unknown = 0,
+           skipped_preambles = 0;   // valid preambles the reference never saw: inside a skipped-over message
+};
+
+// score of one record against the cache (ref: src/dump1090.c:3279-3365)
+int score_record (const Record &r, const IcaoCache &cache);
+// accept rules + repair (ref: src/dump1090.c:2372-2578, 2586-2587, 2676-2687); fills msg/addr/... of `out`.
+// Returns 0, -1 (unknown ICAO), -2 (CRC).  Adds to the cache exactly where the reference does.
+int accept_record (const Record &r, IcaoCache &cache, modes_message *out);
+
+// ref: src/dump1090.c:1427-1432
+inline int len_by_type (int df) { return (df == 16 || df == 17 || df == 19 || df == 20 || df == 21) ? kLongBits : kShortBits; }
+
+// The per-block ordered walk of demod_2400 (ref: src/demod-2400.c:200-520) over records sorted by
+// stream position.  `pos[i]` is the scan position of records[i] inside the shard.
+// sample_rate/first_sample give the block timestamps (ref: src/infile.c:143).
+void accept_pass_2400 (const Record *records, const uint64_t *pos, size_t n, uint32_t block_samples,
+                       uint64_t first_sample, uint32_t sample_rate, IcaoCache &cache, AcceptStats &st,
+                       std::vector<modes_message> &out, std::vector<uint64_t> &out_pos,
+                       const uint64_t *vp_bitmap, uint64_t nsamples);
+
+}  // namespace modes

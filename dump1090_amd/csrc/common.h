@@ -1,0 +1,71 @@
+// Shared definitions between the host side of libmodes_hip.so and its gfx950 kernels.
+#pragma once
+#include <stdint.h>
+
+namespace modes {
+
+constexpr int kShortBytes = 7, kLongBytes = 14, kShortBits = 56, kLongBits = 112;
+constexpr uint32_t kAsyncBufSize = 256 * 1024;       // ref: src/misc.h:649 (bytes per bin_read block)
+constexpr uint32_t kIcaoSlots = 1024;                // ref: src/misc.h:664
+constexpr uint32_t kNonIcao = 1u << 24;              // ref: src/misc.h:699
+
+// Converter rows of converters_table[] (ref: src/convert.c:301-308)
+enum Conv : int {
+  kConvUc8Lut = 0, kConvUc8LutPower = 1, kConvUc8Generic = 2,
+  kConvSc16Int = 3, kConvSc16Generic = 4, kConvSc16Q11Generic = 5
+};
+
+// ---- scan kernel geometry (2.4 MS/s) -------------------------------------------------
+// One wavefront owns one strip of kStrip consecutive scan positions of the stream.
+constexpr int kStrip = 4096;
+constexpr int kLook2400 = 320;     // samples a position may look ahead (<= 290 needed; ref: src/demod-2400.c:339-412,488-494)
+constexpr int kTilePad = 16;       // slack so global loads can start 16-sample aligned
+
+// Candidate classes (what the ordered accept pass needs to know about a record)
+enum Cls : uint8_t {
+  kClsAP = 0,      // DF0/4/5/16/24: address = CRC, score 1000 / -1      (ref: src/dump1090.c:3302-3307)
+  kClsAP2 = 1,     // DF20/21:       address = CRC, score 1000 / -2      (ref: src/dump1090.c:3355-3359)
+  kClsDF11 = 2,    // table hit on syndrome & 0xFFFF80, <= 1 error       (ref: src/dump1090.c:3309-3338)
+  kClsES = 3       // DF17/18 with a table hit                           (ref: src/dump1090.c:3340-3353)
+};
+
+// One candidate that survived every state-independent rejection.  32 bytes.
+struct alignas(16) Record {
+  uint16_t off;        // position inside the strip
+  uint8_t  phase;      // try_phase 4..8 (demod_2400)
+  uint8_t  df;         // msg[0] >> 3
+  uint8_t  cls;        // Cls
+  int8_t   nerr;       // errorinfo.errors (0..2)
+  int8_t   bit0, bit1; // errorinfo.bit[]
+  uint32_t crc;        // crc_checksum over modeS_message_len_by_type(df) bits
+  uint8_t  msg[14];
+  uint8_t  flags;      // filled by the accept pass: bit0 accepted
+  uint8_t  pad[5];
+};
+static_assert(sizeof(Record) == 32, "Record must be 32 bytes");
+
+// Error table entry on the device: sorted by syndrome.
+struct ErrEntry { uint32_t syndrome; int8_t nerr, bit0, bit1, pad; };
+static_assert(sizeof(ErrEntry) == 8, "ErrEntry must be 8 bytes");
+
+struct ScanParams {
+  const uint8_t  *iq;          // device, whole shard
+  uint64_t        nsamples;    // samples in the shard == scan positions
+  const uint16_t *halo;        // `ov` magnitudes that precede sample 0, or nullptr (zeros)
+  uint32_t        ov;          // Modes.trailing_samples (ref: src/dump1090.c:734)
+  uint32_t        block_samples;
+  int32_t         conv;        // Conv
+  int32_t         phase_enhance;
+  const ErrEntry *short_tab;  int32_t short_n;
+  const ErrEntry *long_tab;   int32_t long_n;
+  const uint16_t *lut256;      // as-written uc8 table: mag_lut[byte] (ref: src/convert.c:29)
+  Record         *records;     // [nstrips][cap]
+  uint32_t       *counts;      // [nstrips]
+  uint32_t        cap;
+  uint32_t        nstrips;
+  unsigned long long *stats;   // [0] valid_preamble  [1] records  [2] overflow strips
+  int32_t         write_records;   // 0 = timing variant that keeps everything but the final store
+  uint64_t       *vp_bitmap;       // [nstrips][64]: bit = position reached scoring (Modes.stat.valid_preamble), or nullptr
+};
+
+}  // namespace modes

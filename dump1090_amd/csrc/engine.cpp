@@ -1,0 +1,397 @@
+// Host side of libmodes_hip.so: device set-up, the bulk engine, the C ABI of include/modes_hip.h.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/modes_hip.h"
+#include "accept.h"
+#include "common.h"
+#include "kernels.h"
+#include "tables.h"
+
+using namespace modes;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail (int code, const char *fmt, ...)
+{
+  char buf[512];
+  va_list ap;
+  va_start (ap, fmt);
+  vsnprintf (buf, sizeof buf, fmt, ap);
+  va_end (ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return fail (MODES_E_HIP, "%s: %s", #expr, hipGetErrorString (e_));  \
+  } while (0)
+
+// Per-process, per-device constant tables.
+struct DeviceTables {
+  int device = -1;
+  int fix_bits = -1;
+  ErrEntry *short_tab = nullptr, *long_tab = nullptr;
+  int short_n = 0, long_n = 0;
+  uint16_t *lut256 = nullptr;
+};
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t cap = 0;
+  int reserve (size_t n)
+  {
+    if (n <= cap) return MODES_OK;
+    if (p) (void) hipFree (p);
+    p = nullptr; cap = 0;
+    size_t want = n + n / 8 + 64;
+    hipError_t e = hipMalloc (reinterpret_cast<void **> (&p), want * sizeof (T));
+    if (e != hipSuccess) return fail (MODES_E_NOMEM, "hipMalloc(%zu bytes): %s", want * sizeof (T), hipGetErrorString (e));
+    cap = want;
+    return MODES_OK;
+  }
+  void release () { if (p) (void) hipFree (p); p = nullptr; cap = 0; }
+};
+
+uint32_t trailing_samples (uint32_t rate)     // ref: src/dump1090.c:734
+{
+  return uint32_t ((8 + 112 + 16) * 1E-6 * rate);
+}
+
+int bytes_per_sample (int fmt) { return fmt == INPUT_UC8 ? 2 : 4; }
+
+// converters_table walk of convert_init (ref: src/convert.c:294-328)
+int select_converter (int fmt, bool dc, bool power)
+{
+  static const struct { int fmt; bool dc, pw; } rows[6] = {
+    { INPUT_UC8, false, false }, { INPUT_UC8, false, true }, { INPUT_UC8, true, true },
+    { INPUT_SC16, false, false }, { INPUT_SC16, true, true }, { INPUT_SC16Q11, true, true } };
+  for (int i = 0; i < 6; i++) {
+    if (rows[i].fmt != fmt) continue;
+    if (dc && !rows[i].dc) continue;
+    if (power && !rows[i].pw) continue;
+    return i;
+  }
+  return -1;
+}
+
+}  // namespace
+
+struct modes_engine {
+  modes_engine_config cfg;
+  int conv = -1;
+  uint32_t ov = 0, block_samples = 0;
+  CrcTables crc;
+  DeviceTables tabs;
+  IcaoCache cache;
+  // device buffers
+  DevBuf<Record> records, packed;
+  DevBuf<uint32_t> counts, rssi_len;
+  DevBuf<uint64_t> chunk_sum, packed_pos, offsets, rssi_pos, rssi_sum, vp_bitmap;
+  DevBuf<uint8_t> staging;                  // for run_host
+  DevBuf<uint16_t> tail;
+  unsigned long long *d_stats = nullptr;
+  uint32_t cap = 0;
+  // results
+  std::vector<modes_message> messages;
+  modes_stats stats;
+};
+
+namespace {
+
+int setup_tables (modes_engine *e)
+{
+  DeviceTables &t = e->tabs;
+  e->crc.build (e->cfg.fix_bits);
+  float uc8f[256];
+  build_uc8_float_lut (uc8f);
+  HIP_TRY (upload_constants (e->crc.single_bit (), uc8f));
+  uint16_t lut[256];
+  build_uc8_byte_lut (lut);
+  HIP_TRY (hipMalloc (reinterpret_cast<void **> (&t.lut256), sizeof lut));
+  HIP_TRY (hipMemcpy (t.lut256, lut, sizeof lut, hipMemcpyHostToDevice));
+  for (int bits : { kShortBits, kLongBits }) {
+    std::vector<ErrEntry> d = e->crc.device_table (bits);
+    ErrEntry *p = nullptr;
+    if (d.size () > 4096) return fail (MODES_E_ARG, "error table too large (%zu)", d.size ());
+    if (!d.empty ()) {
+      HIP_TRY (hipMalloc (reinterpret_cast<void **> (&p), d.size () * sizeof (ErrEntry)));
+      HIP_TRY (hipMemcpy (p, d.data (), d.size () * sizeof (ErrEntry), hipMemcpyHostToDevice));
+    }
+    if (bits == kShortBits) { t.short_tab = p; t.short_n = int (d.size ()); }
+    else                    { t.long_tab = p;  t.long_n = int (d.size ()); }
+  }
+  HIP_TRY (hipMalloc (reinterpret_cast<void **> (&e->d_stats), 8 * sizeof (unsigned long long)));
+  return MODES_OK;
+}
+
+int fill_scan_params (modes_engine *e, const void *d_iq, size_t nbytes, const uint16_t *d_halo, ScanParams *sp)
+{
+  const uint64_t nsamples = nbytes / bytes_per_sample (e->cfg.input_format);
+  const uint64_t nstrips64 = (nsamples + kStrip - 1) / kStrip;
+  if (nstrips64 > 0x7FFFFFFFull) return fail (MODES_E_ARG, "shard too large");
+  const uint32_t nstrips = uint32_t (nstrips64);
+  int rc;
+  if ((rc = e->records.reserve (size_t (nstrips) * e->cap)) != MODES_OK) return rc;
+  if ((rc = e->counts.reserve (nstrips)) != MODES_OK) return rc;
+  if ((rc = e->vp_bitmap.reserve (size_t (nstrips) * 64)) != MODES_OK) return rc;
+  memset (sp, 0, sizeof *sp);
+  sp->iq = static_cast<const uint8_t *> (d_iq);
+  sp->nsamples = nsamples;
+  sp->halo = d_halo;
+  sp->ov = e->ov;
+  sp->block_samples = e->block_samples;
+  sp->conv = e->conv;
+  sp->phase_enhance = e->cfg.phase_enhance;
+  sp->short_tab = e->tabs.short_tab; sp->short_n = e->tabs.short_n;
+  sp->long_tab = e->tabs.long_tab;   sp->long_n = e->tabs.long_n;
+  sp->lut256 = e->tabs.lut256;
+  sp->records = e->records.p;
+  sp->counts = e->counts.p;
+  sp->cap = e->cap;
+  sp->nstrips = nstrips;
+  sp->stats = e->d_stats;
+  sp->write_records = 1;
+  sp->vp_bitmap = e->vp_bitmap.p;
+  return MODES_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *modes_last_error (void) { return g_err.c_str (); }
+
+int modes_engine_create (const modes_engine_config *cfg, modes_engine **out)
+{
+  if (!cfg || !out) return fail (MODES_E_ARG, "null argument");
+  *out = nullptr;
+  if (cfg->sample_rate != 2400000)
+    return fail (MODES_E_ARG, "sample rate %u: only the 2.4 MS/s path is built so far", cfg->sample_rate);
+  const int conv = select_converter (cfg->input_format, cfg->filter_dc != 0, cfg->compute_power != 0);
+  if (conv < 0) return fail (MODES_E_ARG, "no suitable converter for format=%d power=%d DC=%d", cfg->input_format,
+                             cfg->compute_power, cfg->filter_dc);
+  if (cfg->filter_dc) return fail (MODES_E_ARG, "DC-filter converters are not built yet");
+  int ndev = 0;
+  if (hipGetDeviceCount (&ndev) != hipSuccess || ndev <= 0) return fail (MODES_E_NODEVICE, "no HIP device");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail (MODES_E_ARG, "device %d of %d", cfg->device, ndev);
+  HIP_TRY (hipSetDevice (cfg->device));
+
+  modes_engine *e = new modes_engine ();
+  e->cfg = *cfg;
+  e->conv = conv;
+  e->ov = trailing_samples (cfg->sample_rate);
+  e->block_samples = kAsyncBufSize / bytes_per_sample (cfg->input_format);
+  e->cap = cfg->phase_enhance ? 256 : 64;
+  memset (&e->stats, 0, sizeof e->stats);
+  int rc = setup_tables (e);
+  if (rc != MODES_OK) { modes_engine_destroy (e); return rc; }
+  rc = e->tail.reserve (e->ov);
+  if (rc != MODES_OK) { modes_engine_destroy (e); return rc; }
+  *out = e;
+  return MODES_OK;
+}
+
+void modes_engine_destroy (modes_engine *e)
+{
+  if (!e) return;
+  e->records.release (); e->packed.release (); e->counts.release (); e->rssi_len.release ();
+  e->chunk_sum.release (); e->packed_pos.release (); e->offsets.release (); e->rssi_pos.release ();
+  e->rssi_sum.release (); e->staging.release (); e->tail.release (); e->vp_bitmap.release ();
+  if (e->tabs.short_tab) (void) hipFree (e->tabs.short_tab);
+  if (e->tabs.long_tab) (void) hipFree (e->tabs.long_tab);
+  if (e->tabs.lut256) (void) hipFree (e->tabs.lut256);
+  if (e->d_stats) (void) hipFree (e->d_stats);
+  delete e;
+}
+
+int modes_engine_set_icao (modes_engine *e, const uint32_t *slots)
+{
+  if (!e) return fail (MODES_E_ARG, "null engine");
+  if (slots) memcpy (e->cache.raw (), slots, sizeof (uint32_t) * kIcaoSlots); else e->cache.clear ();
+  return MODES_OK;
+}
+
+int modes_engine_get_icao (modes_engine *e, uint32_t *slots)
+{
+  if (!e || !slots) return fail (MODES_E_ARG, "null argument");
+  memcpy (slots, e->cache.raw (), sizeof (uint32_t) * kIcaoSlots);
+  return MODES_OK;
+}
+
+int modes_engine_run_device (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t first_sample,
+                             const uint16_t *d_halo, void *stream_v)
+{
+  if (!e || (!d_iq && nbytes)) return fail (MODES_E_ARG, "null argument");
+  hipStream_t stream = static_cast<hipStream_t> (stream_v);
+  if (first_sample % e->block_samples) return fail (MODES_E_ARG, "first_sample must be a multiple of the block length");
+  HIP_TRY (hipSetDevice (e->cfg.device));
+  e->messages.clear ();
+  memset (&e->stats, 0, sizeof e->stats);
+
+  ScanParams sp;
+  int rc = fill_scan_params (e, d_iq, nbytes, d_halo, &sp);
+  if (rc != MODES_OK) return rc;
+  if (sp.nstrips == 0) return MODES_OK;
+
+  HIP_TRY (hipMemsetAsync (e->d_stats, 0, 8 * sizeof (unsigned long long), stream));
+  HIP_TRY (launch_scan2400 (sp, stream));
+
+  // compact the per-strip slots into one ordered list
+  const uint32_t nchunks = (sp.nstrips + 1023) / 1024;
+  if ((rc = e->chunk_sum.reserve (nchunks + 2)) != MODES_OK) return rc;
+  if ((rc = e->offsets.reserve (sp.nstrips)) != MODES_OK) return rc;
+  unsigned long long st[8];
+  HIP_TRY (hipMemcpyAsync (st, e->d_stats, sizeof st, hipMemcpyDeviceToHost, stream));
+  HIP_TRY (hipStreamSynchronize (stream));
+  if (st[2]) return fail (MODES_E_OVERFLOW, "%llu strips overflowed their candidate slots (cap %u)", st[2], e->cap);
+  const size_t nrec = size_t (st[1]);
+  e->stats.valid_preamble = st[0];
+  e->stats.candidates = nrec;
+  if ((rc = e->packed.reserve (nrec + 1)) != MODES_OK) return rc;
+  if ((rc = e->packed_pos.reserve (nrec + 1)) != MODES_OK) return rc;
+  HIP_TRY (launch_compact (e->counts.p, sp.nstrips, e->chunk_sum.p, e->records.p, e->cap, e->packed.p, e->packed_pos.p,
+                           e->offsets.p, stream));
+
+  std::vector<Record> recs (nrec);
+  std::vector<uint64_t> pos (nrec);
+  std::vector<uint64_t> vp (size_t (sp.nstrips) * 64);
+  HIP_TRY (hipMemcpyAsync (vp.data (), e->vp_bitmap.p, vp.size () * sizeof (uint64_t), hipMemcpyDeviceToHost, stream));
+  if (nrec) {
+    HIP_TRY (hipMemcpyAsync (recs.data (), e->packed.p, nrec * sizeof (Record), hipMemcpyDeviceToHost, stream));
+    HIP_TRY (hipMemcpyAsync (pos.data (), e->packed_pos.p, nrec * sizeof (uint64_t), hipMemcpyDeviceToHost, stream));
+  }
+  HIP_TRY (hipStreamSynchronize (stream));
+
+  // ordered accept pass
+  AcceptStats as;
+  std::vector<uint64_t> mpos;
+  accept_pass_2400 (recs.data (), pos.data (), nrec, e->block_samples, first_sample, e->cfg.sample_rate, e->cache, as,
+                    e->messages, mpos, vp.data (), sp.nsamples);
+  e->stats.valid_preamble -= as.skipped_preambles;
+  e->stats.demodulated = as.demodulated; e->stats.out_of_phase = as.out_of_phase;
+  e->stats.CRC_good = as.CRC_good; e->stats.CRC_bad = as.CRC_bad; e->stats.CRC_fixed = as.CRC_fixed;
+  e->stats.CRC_single_bit_fix = as.CRC_single_bit_fix; e->stats.CRC_two_bits_fix = as.CRC_two_bits_fix;
+  e->stats.demod_rejected_unknown = as.rejected_unknown;
+  e->stats.replay_rounds = 0;
+
+  // signal level of the accepted messages (ref: src/demod-2400.c:486-497)
+  const size_t nm = e->messages.size ();
+  if (nm) {
+    std::vector<uint32_t> len (nm);
+    std::vector<uint64_t> sums (nm);
+    for (size_t i = 0; i < nm; i++) len[i] = uint32_t (e->messages[i].msg_bits) * 12 / 5;
+    if ((rc = e->rssi_pos.reserve (nm)) != MODES_OK) return rc;
+    if ((rc = e->rssi_len.reserve (nm)) != MODES_OK) return rc;
+    if ((rc = e->rssi_sum.reserve (nm)) != MODES_OK) return rc;
+    HIP_TRY (hipMemcpyAsync (e->rssi_pos.p, mpos.data (), nm * sizeof (uint64_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY (hipMemcpyAsync (e->rssi_len.p, len.data (), nm * sizeof (uint32_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY (launch_rssi2400 (e->conv, sp.iq, sp.nsamples, sp.halo, sp.ov, sp.block_samples, sp.lut256, e->rssi_pos.p,
+                              e->rssi_len.p, e->rssi_sum.p, uint32_t (nm), stream));
+    HIP_TRY (hipMemcpyAsync (sums.data (), e->rssi_sum.p, nm * sizeof (uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY (hipStreamSynchronize (stream));
+    for (size_t i = 0; i < nm; i++) {
+      const double signal_power = double (sums[i]) / 65535.0 / 65535.0;
+      e->messages[i].sig_level = signal_power / double (len[i]);
+    }
+  }
+  return MODES_OK;
+}
+
+int modes_engine_run_host (modes_engine *e, const void *iq, size_t nbytes, uint64_t first_sample)
+{
+  if (!e || (!iq && nbytes)) return fail (MODES_E_ARG, "null argument");
+  HIP_TRY (hipSetDevice (e->cfg.device));
+  int rc = e->staging.reserve (nbytes + 64);
+  if (rc != MODES_OK) return rc;
+  HIP_TRY (hipMemcpy (e->staging.p, iq, nbytes, hipMemcpyHostToDevice));
+  return modes_engine_run_device (e, e->staging.p, nbytes, first_sample, nullptr, nullptr);
+}
+
+int modes_engine_time_scan (modes_engine *e, const void *d_iq, size_t nbytes, int reps, void *stream_v, float *ms_out)
+{
+  if (!e || !d_iq || reps <= 0 || !ms_out) return fail (MODES_E_ARG, "bad argument");
+  hipStream_t stream = static_cast<hipStream_t> (stream_v);
+  HIP_TRY (hipSetDevice (e->cfg.device));
+  ScanParams sp;
+  int rc = fill_scan_params (e, d_iq, nbytes, nullptr, &sp);
+  if (rc != MODES_OK) return rc;
+  hipEvent_t a, b;
+  HIP_TRY (hipEventCreate (&a));
+  HIP_TRY (hipEventCreate (&b));
+  HIP_TRY (hipMemsetAsync (e->d_stats, 0, 8 * sizeof (unsigned long long), stream));
+  HIP_TRY (hipEventRecord (a, stream));
+  for (int i = 0; i < reps; i++) HIP_TRY (launch_scan2400 (sp, stream));
+  HIP_TRY (hipEventRecord (b, stream));
+  HIP_TRY (hipEventSynchronize (b));
+  float ms = 0;
+  HIP_TRY (hipEventElapsedTime (&ms, a, b));
+  (void) hipEventDestroy (a);
+  (void) hipEventDestroy (b);
+  *ms_out = ms / float (reps);
+  return MODES_OK;
+}
+
+size_t modes_engine_num_messages (const modes_engine *e) { return e ? e->messages.size () : 0; }
+const modes_message *modes_engine_messages (const modes_engine *e) { return e && !e->messages.empty () ? e->messages.data () : nullptr; }
+
+int modes_engine_get_stats (const modes_engine *e, modes_stats *out)
+{
+  if (!e || !out) return fail (MODES_E_ARG, "null argument");
+  *out = e->stats;
+  return MODES_OK;
+}
+
+const uint16_t *modes_engine_tail_halo (const modes_engine *e) { return e ? e->tail.p : nullptr; }
+
+int modes_convert_device (int conv, const void *d_iq, uint16_t *d_mag, size_t nsamples, convert_state *state,
+                          double *out_power, void *stream_v)
+{
+  (void) state;
+  hipStream_t stream = static_cast<hipStream_t> (stream_v);
+  if (conv < 0 || conv > 5) return fail (MODES_E_ARG, "converter id %d", conv);
+  static uint16_t *d_lut = nullptr;
+  static unsigned long long *d_power = nullptr;
+  static bool consts = false;
+  if (!d_lut) {
+    uint16_t lut[256];
+    build_uc8_byte_lut (lut);
+    HIP_TRY (hipMalloc (reinterpret_cast<void **> (&d_lut), sizeof lut));
+    HIP_TRY (hipMemcpy (d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
+    HIP_TRY (hipMalloc (reinterpret_cast<void **> (&d_power), sizeof (unsigned long long)));
+  }
+  if (!consts) {
+    CrcTables t;
+    float uc8f[256];
+    build_uc8_float_lut (uc8f);
+    HIP_TRY (upload_constants (t.single_bit (), uc8f));
+    consts = true;
+  }
+  if (state && (state->DC_A != 0.0f || state->DC_B != 1.0f) && conv != kConvUc8Lut && conv != kConvUc8LutPower && conv != kConvSc16Int)
+    return fail (MODES_E_ARG, "DC-filter converters are not built yet");
+  HIP_TRY (hipMemsetAsync (d_power, 0, sizeof (unsigned long long), stream));
+  HIP_TRY (launch_convert (conv, static_cast<const uint8_t *> (d_iq), d_mag, nsamples, d_lut, d_power, stream));
+  if (out_power) {
+    unsigned long long pw = 0;
+    HIP_TRY (hipMemcpyAsync (&pw, d_power, sizeof pw, hipMemcpyDeviceToHost, stream));
+    HIP_TRY (hipStreamSynchronize (stream));
+    *out_power = conv == kConvUc8LutPower ? double (pw) / 65535.0 / 65535.0 : 0.0;
+  }
+  return MODES_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,16 @@
+// Launchers implemented in kernels.hip.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include "common.h"
+
+namespace modes {
+hipError_t upload_constants (const uint32_t *single_bit, const float *uc8_float);
+hipError_t launch_scan2400 (const ScanParams &p, hipStream_t stream);
+hipError_t launch_convert (int conv, const uint8_t *iq, uint16_t *mag, size_t n, const uint16_t *lut256,
+                           unsigned long long *power_u64, hipStream_t stream);
+hipError_t launch_rssi2400 (int conv, const uint8_t *iq, uint64_t nsamples, const uint16_t *halo, uint32_t ov,
+                            uint32_t block_samples, const uint16_t *lut256, const uint64_t *pos, const uint32_t *len,
+                            uint64_t *sum_out, uint32_t nmsg, hipStream_t stream);
+hipError_t launch_compact (const uint32_t *counts, uint32_t nstrips, uint64_t *chunk_sum, const Record *records,
+                           uint32_t cap, Record *packed, uint64_t *packed_pos, uint64_t *offsets, hipStream_t stream);
+}

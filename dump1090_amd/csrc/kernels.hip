@@ -1,0 +1,661 @@
+// gfx950 kernels of libmodes_hip.so.
+//
+// scan2400: IQ bytes in HBM -> (magnitudes only ever live in LDS) -> preamble detect ->
+//           phase pick -> bit slicing -> CRC syndrome -> error-table diagnose -> records.
+//
+// One wavefront (64 lanes) owns one strip of kStrip scan positions.  No __syncthreads():
+// every LDS buffer is private to a wave, all hand-offs are wave-synchronous.
+//
+// "ref:" citations are relative to the reference's root.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "common.h"
+
+namespace modes {
+
+__constant__ uint32_t c_single_bit[kLongBits];     // ref: src/crc.c:35,56-61
+__constant__ float    c_uc8_float[256];            // (float)((b-127.5)/127.5), ref: src/convert.c:132
+
+using u64 = unsigned long long;
+
+// ------------------------------------------------------------------------------------------
+// converters, one sample
+// ------------------------------------------------------------------------------------------
+
+// ref: src/convert.c:254-292
+__device__ __forceinline__ uint16_t mag_sc16_int (int i16, int q16)
+{
+  uint32_t I = uint32_t (i16 < 0 ? -i16 : i16), Q = uint32_t (q16 < 0 ? -q16 : q16), mag;
+  if (I < Q) mag = (I < ((106u * Q) >> 8)) ? (12868u * I + 64692u * Q) >> 16 : (36646u * I + 54842u * Q) >> 16;
+  else       mag = (I < ((618u * Q) >> 8)) ? (54842u * I + 36646u * Q) >> 16 : (64692u * I + 12868u * Q) >> 16;
+  return uint16_t (mag);
+}
+
+// ref: src/convert.c:142-147 -- the tail shared by the three float converters, DC block already applied
+__device__ __forceinline__ uint16_t mag_from_float (float fI, float fQ, float *mag_sq_out)
+{
+  float mag_sq = __fadd_rn (__fmul_rn (fI, fI), __fmul_rn (fQ, fQ));
+  if (mag_sq > 1.0f) mag_sq = 1.0f;
+  if (mag_sq_out) *mag_sq_out = mag_sq;
+  const double v = __dadd_rn (__dmul_rn (double (sqrtf (mag_sq)), 65535.0), 0.5);
+  return uint16_t (int (v));
+}
+
+// ------------------------------------------------------------------------------------------
+// wave helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id () { return int (__builtin_amdgcn_mbcnt_hi (~0u, __builtin_amdgcn_mbcnt_lo (~0u, 0u))); }
+
+__device__ __forceinline__ int wave_incl_scan (int v, int lane)
+{
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int o = __shfl_up (v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+__device__ __forceinline__ uint32_t wave_xor (uint32_t v)
+{
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v ^= uint32_t (__shfl_xor (int (v), d, 64));
+  return v;
+}
+
+__device__ __forceinline__ u64 funnel (u64 w, u64 nx, int k) { return (w >> k) | (nx << (64 - k)); }
+
+// per-byte bit reversal of a 32-bit word (message bit k sits at mask bit k, MSB-first bytes wanted)
+__device__ __forceinline__ uint32_t rev_in_bytes (uint32_t x) { return __builtin_bswap32 (__brev (x)); }
+
+// ------------------------------------------------------------------------------------------
+// 2.4 MS/s slicers.  A data bit that starts `f` fifths of a sample after m[0] is sliced at
+// sample f/5 with the weights of row f%5 (ref: src/demod-2400.c:32-55, 339-412).
+// ------------------------------------------------------------------------------------------
+template <int F>
+__device__ __forceinline__ int slice_const (const int *s)   // s[] = samples as ints, compile-time position
+{
+  constexpr int i = F / 5, r = F % 5;
+  if (r == 0) return 5 * s[i] - 3 * s[i + 1] - 2 * s[i + 2];
+  if (r == 1) return 4 * s[i] - s[i + 1] - 3 * s[i + 2];
+  if (r == 2) return 3 * s[i] + s[i + 1] - 4 * s[i + 2];
+  if (r == 3) return 2 * s[i] + 3 * s[i + 1] - 5 * s[i + 2];
+  return s[i] + 5 * s[i + 1] - 5 * s[i + 2] - s[i + 3];
+}
+template <int R> __device__ __forceinline__ constexpr int corr_weight () { return R == 0 ? 26 : R == 1 ? 38 : R == 2 ? 38 : R == 3 ? 26 : 19; }
+
+// correlate_check for start phase T over the first five bits (ref: src/demod-2400.c:86-129);
+// also returns those five sliced bits (bit 4 = first data bit).
+template <int T>
+__device__ __forceinline__ int check_phase (const int *s, int *five_bits)
+{
+  const int a = slice_const<T> (s), b = slice_const<T + 12> (s), c = slice_const<T + 24> (s),
+            d = slice_const<T + 36> (s), e = slice_const<T + 48> (s);
+  *five_bits = ((a > 0) << 4) | ((b > 0) << 3) | ((c > 0) << 2) | ((d > 0) << 1) | (e > 0);
+  return abs (a * corr_weight<T % 5> ()) + abs (b * corr_weight<(T + 12) % 5> ()) + abs (c * corr_weight<(T + 24) % 5> ()) +
+         abs (d * corr_weight<(T + 36) % 5> ()) + abs (e * corr_weight<(T + 48) % 5> ());
+}
+
+// bytes sliced for a DF (ref: src/demod-2400.c:416-435): 7, 14 or 0 (= give up after byte 0)
+__device__ __forceinline__ int slice_bytes_for_df (int df)
+{
+  const uint32_t short_set = (1u << 0) | (1u << 4) | (1u << 5) | (1u << 11);
+  const uint32_t long_set = (1u << 16) | (1u << 17) | (1u << 18) | (1u << 20) | (1u << 21) | (1u << 24);
+  return ((short_set >> df) & 1) ? kShortBytes : ((long_set >> df) & 1) ? kLongBytes : 0;
+}
+// ref: src/dump1090.c:1427-1432
+__device__ __forceinline__ int msg_bits_for_df (int df)
+{
+  return (df == 16 || df == 17 || df == 19 || df == 20 || df == 21) ? kLongBits : kShortBits;
+}
+
+// Wave-cooperative search of a sorted error table (n <= 4096): two probes per lane.
+__device__ __forceinline__ int table_find (const ErrEntry *tab, int n, uint32_t syn, int lane)
+{
+  if (n <= 0) return -1;
+  const int step = (n + 63) >> 6;
+  const int first = lane * step;
+  const bool le = first < n && tab[first].syndrome <= syn;
+  const u64 m = __ballot (le);
+  if (!m) return -1;
+  const int seg = 63 - __builtin_clzll (m);       // `le` is monotone in the lane index
+  const int idx = seg * step + lane;
+  const bool eq = lane < step && idx < n && tab[idx].syndrome == syn;
+  const u64 h = __ballot (eq);
+  return h ? seg * step + int (__builtin_ctzll (h)) : -1;
+}
+
+// LDS per wave
+struct WaveLds {
+  uint16_t tile[kStrip + kLook2400 + kTilePad];   // magnitudes V[P0 - shift ...]
+  uint16_t q1[2048];                              // off | pattern << 12
+  uint32_t q2[1024];                              // off | (t-4) << 12 | df << 16
+  uint16_t lut[256];                              // as-written uc8 table
+  uint32_t sb[kLongBits];
+  u64      vp[64];                                // valid-preamble bit per position of the strip
+};
+
+constexpr int kWavesPerBlock = 4;
+
+// ------------------------------------------------------------------------------------------
+// staging: convert samples [a_lo, a_lo + count) into w.tile[0 .. count)
+// ------------------------------------------------------------------------------------------
+template <int CONV>
+__device__ __forceinline__ void stage_tile (WaveLds &w, const ScanParams &p, long long a_lo, int count, int lane)
+{
+  const long long N = (long long) p.nsamples;
+  for (int c = lane * 8; c < count; c += 64 * 8) {
+    const long long n0 = a_lo + c;
+    uint16_t out[8];
+    if (n0 >= 0 && n0 + 8 <= N) {
+      if (CONV == kConvUc8Lut || CONV == kConvUc8LutPower) {
+        // as written: output sample i of a block reads input BYTE i of that block (ref: src/convert.c:19,29)
+        const uint64_t blk = uint64_t (n0) / p.block_samples, i = uint64_t (n0) % p.block_samples;
+        const uint2 v = *reinterpret_cast<const uint2 *> (p.iq + blk * 2 * p.block_samples + i);
+        const uint32_t d[2] = { v.x, v.y };
+#pragma unroll
+        for (int k = 0; k < 8; k++) out[k] = w.lut[(d[k >> 2] >> (8 * (k & 3))) & 0xFF];
+      } else if (CONV == kConvUc8Generic) {
+        const uint4 v = *reinterpret_cast<const uint4 *> (p.iq + 2 * n0);
+        const uint32_t d[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const uint32_t iqp = d[k >> 1] >> (16 * (k & 1));
+          out[k] = mag_from_float (c_uc8_float[iqp & 0xFF], c_uc8_float[(iqp >> 8) & 0xFF], nullptr);
+        }
+      } else {
+        const uint4 *src = reinterpret_cast<const uint4 *> (p.iq + 4 * n0);
+        const uint4 v0 = src[0], v1 = src[1];
+        const uint32_t d[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int I = int (int16_t (d[k] & 0xFFFF)), Q = int (int16_t (d[k] >> 16));
+          if (CONV == kConvSc16Int) out[k] = mag_sc16_int (I, Q);
+          else {
+            const float sc = CONV == kConvSc16Generic ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
+            out[k] = mag_from_float (float (I) * sc, float (Q) * sc, nullptr);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const long long n = n0 + k;
+        uint16_t m = 0;
+        if (n < 0) {
+          if (p.halo && n + (long long) p.ov >= 0) m = p.halo[n + (long long) p.ov];
+        } else if (n < N) {
+          if (CONV == kConvUc8Lut || CONV == kConvUc8LutPower) {
+            const uint64_t blk = uint64_t (n) / p.block_samples, i = uint64_t (n) % p.block_samples;
+            m = w.lut[p.iq[blk * 2 * p.block_samples + i]];
+          } else if (CONV == kConvUc8Generic) {
+            m = mag_from_float (c_uc8_float[p.iq[2 * n]], c_uc8_float[p.iq[2 * n + 1]], nullptr);
+          } else {
+            const int16_t *s = reinterpret_cast<const int16_t *> (p.iq) + 2 * n;
+            if (CONV == kConvSc16Int) m = mag_sc16_int (s[0], s[1]);
+            else {
+              const float sc = CONV == kConvSc16Generic ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
+              m = mag_from_float (float (s[0]) * sc, float (s[1]) * sc, nullptr);
+            }
+          }
+        }
+        out[k] = m;
+      }
+    }
+    uint4 pk;
+    pk.x = out[0] | (uint32_t (out[1]) << 16); pk.y = out[2] | (uint32_t (out[3]) << 16);
+    pk.z = out[4] | (uint32_t (out[5]) << 16); pk.w = out[6] | (uint32_t (out[7]) << 16);
+    *reinterpret_cast<uint4 *> (&w.tile[c]) = pk;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// the scan kernel
+// ------------------------------------------------------------------------------------------
+template <int CONV>
+__global__ __launch_bounds__ (64 * kWavesPerBlock)
+void scan2400_kernel (const ScanParams p)
+{
+  __shared__ WaveLds lds[kWavesPerBlock];
+  const int lane = lane_id ();
+  const int wv = threadIdx.x >> 6;
+  WaveLds &w = lds[wv];
+  const uint32_t strip = blockIdx.x * kWavesPerBlock + wv;
+  if (strip >= p.nstrips) return;
+
+  // wave-private tables
+  for (int i = lane; i < 256; i += 64) w.lut[i] = p.lut256 ? p.lut256[i] : uint16_t (0);
+  for (int i = lane; i < kLongBits; i += 64) w.sb[i] = c_single_bit[i];
+  w.vp[lane] = 0;
+
+  // ---- stage A: magnitudes of V[P0 .. P0 + kStrip + kLook2400) into LDS ----
+  const long long P0 = (long long) strip * kStrip;
+  const long long s0 = P0 - (long long) p.ov;                 // first sample index needed (may be < 0)
+  const long long a_lo = (s0 >= 0 ? s0 : s0 - 15) / 16 * 16;  // floor to a multiple of 16
+  const int shift = int (s0 - a_lo);                          // V[P0 + x] == tile[x + shift]
+  stage_tile<CONV> (w, p, a_lo, kStrip + kLook2400 + kTilePad, lane);
+  __builtin_amdgcn_s_waitcnt (0xc07f);   // lgkmcnt(0): LDS writes of this wave are done (wave-private data)
+  __builtin_amdgcn_wave_barrier ();
+
+  const uint16_t *V = w.tile + shift;
+
+  // ---- stage B: LT/GT bit planes; lane l ends up owning word l = positions [64 l, 64 l + 64) ----
+  uint32_t lt_lo = 0, lt_hi = 0, gt_lo = 0, gt_hi = 0;
+  u64 lt_last = 0, gt_last = 0;
+#pragma unroll 5
+  for (int s = 0; s <= 64; s++) {
+    const int x = 64 * s + lane;
+    const uint32_t a = V[x], b = V[x + 1];
+    const u64 lt = __ballot (a < b), gt = __ballot (a > b);
+    if (s < 64) {
+      if (lane == s) { lt_lo = uint32_t (lt); lt_hi = uint32_t (lt >> 32); gt_lo = uint32_t (gt); gt_hi = uint32_t (gt >> 32); }
+    } else { lt_last = lt; gt_last = gt; }
+  }
+  const u64 LT = (u64 (lt_hi) << 32) | lt_lo, GT = (u64 (gt_hi) << 32) | gt_lo;
+  u64 LTn = (u64 (uint32_t (__shfl_down (int (lt_hi), 1, 64))) << 32) | uint32_t (__shfl_down (int (lt_lo), 1, 64));
+  u64 GTn = (u64 (uint32_t (__shfl_down (int (gt_hi), 1, 64))) << 32) | uint32_t (__shfl_down (int (gt_lo), 1, 64));
+  if (lane == 63) { LTn = lt_last; GTn = gt_last; }
+
+  // peaks P_k = (p[k] < p[k+1] > p[k+2]); the five layouts of ref: src/demod-2400.c:225-282 with the
+  // quick check (p0 < p1, p12 > p13) folded in.
+#define LTk(k) funnel (LT, LTn, k)
+#define GTk(k) funnel (GT, GTn, k)
+  const u64 P0m = LT & GTk (1), P2m = LTk (2) & GTk (3), P8m = LTk (8) & GTk (9), P11m = LTk (11) & GTk (12);
+  const u64 P3m = LTk (3) & GTk (4), P9m = LTk (9) & GTk (10);
+  const u64 t389 = P0m & P2m & P8m;
+  const u64 ph3 = t389 & LTk (10) & GTk (12);
+  const u64 ph4 = t389 & P11m;
+  const u64 ph5 = P0m & P11m & LTk (2) & GTk (4) & LTk (8) & GTk (10);
+  const u64 u39b = P3m & P9m & P11m;
+  const u64 ph6 = P0m & u39b;
+  const u64 ph7 = LT & GTk (2) & u39b;
+#undef LTk
+#undef GTk
+  u64 any = ph3 | ph4 | ph5 | ph6 | ph7;
+  {   // positions at or beyond the end of the stream are not scanned (ref: src/demod-2400.c:200)
+    const long long base = P0 + 64ll * lane, N = (long long) p.nsamples;
+    if (base >= N) any = 0;
+    else if (base + 64 > N) any &= (~0ull) >> (64 - int (N - base));
+  }
+
+  // ---- queue 1: candidate positions in ascending order ----
+  const int mycnt = __popcll (any);
+  const int incl = wave_incl_scan (mycnt, lane);
+  const int n1 = __shfl (incl, 63, 64);
+  bool overflow = n1 > 2048;
+  if (!overflow) {
+    int slot = incl - mycnt;
+    u64 mm = any;
+    while (mm) {
+      const int b = __builtin_ctzll (mm);
+      const u64 bit = 1ull << b;
+      mm &= mm - 1;
+      const int pat = (ph3 & bit) ? 0 : (ph4 & bit) ? 1 : (ph5 & bit) ? 2 : (ph6 & bit) ? 3 : 4;
+      w.q1[slot++] = uint16_t ((64 * lane + b) | (pat << 12));
+    }
+  }
+  __builtin_amdgcn_s_waitcnt (0xc07f);
+  __builtin_amdgcn_wave_barrier ();
+
+  // ---- stage C: amplitude tests + phase pick, one lane per candidate ----
+  int n2 = 0;
+  uint32_t valid_preamble = 0;
+  for (int base = 0; base < n1 && !overflow; base += 64) {
+    const int qi = base + lane;
+    bool pass = false;
+    int off = 0, nent = 0;
+    uint32_t ent[5];
+    if (qi < n1) {
+      const uint32_t e = w.q1[qi];
+      off = e & 0xFFF;
+      const int pat = e >> 12;
+      const uint16_t *pp = V + off;
+      int s[19];
+#pragma unroll
+      for (int k = 0; k < 19; k++) s[k] = pp[k];
+      int high; uint32_t sig, noise;
+      switch (pat) {     // ref: src/demod-2400.c:233-281
+        case 0:  high = (s[1] + s[3] + s[9] + s[11] + s[12]) / 4; sig = s[1] + s[3] + s[9]; noise = s[5] + s[6] + s[7]; break;
+        case 1:  high = (s[1] + s[3] + s[9] + s[12]) / 4; sig = s[1] + s[3] + s[9] + s[12]; noise = s[5] + s[6] + s[7] + s[8]; break;
+        case 2:  high = (s[1] + s[3] + s[4] + s[9] + s[10] + s[12]) / 4; sig = s[1] + s[12]; noise = s[6] + s[7]; break;
+        case 3:  high = (s[1] + s[4] + s[10] + s[12]) / 4; sig = s[1] + s[4] + s[10] + s[12]; noise = s[5] + s[6] + s[7] + s[8]; break;
+        default: high = (s[1] + s[2] + s[4] + s[10] + s[12]) / 4; sig = s[4] + s[10] + s[12]; noise = s[6] + s[7] + s[8]; break;
+      }
+      pass = !(sig * 2 < 3 * noise) &&                                                  // ref: :292
+             s[5] < high && s[6] < high && s[7] < high && s[8] < high && s[14] < high &&
+             s[15] < high && s[16] < high && s[17] < high && s[18] < high;              // ref: :297-308
+      if (pass) {
+        int d[15];
+#pragma unroll
+        for (int k = 0; k < 15; k++) d[k] = pp[19 + k];
+        int fb[5], cv[5];
+        cv[0] = check_phase<4> (d, &fb[0]); cv[1] = check_phase<5> (d, &fb[1]); cv[2] = check_phase<6> (d, &fb[2]);
+        cv[3] = check_phase<7> (d, &fb[3]); cv[4] = check_phase<8> (d, &fb[4]);
+        if (p.phase_enhance) {                                                          // ref: :310-314
+#pragma unroll
+          for (int t = 0; t < 5; t++)
+            if (slice_bytes_for_df (fb[t])) ent[nent++] = uint32_t (off) | (uint32_t (t) << 12) | (uint32_t (fb[t]) << 16);
+        } else {                                                                        // ref: :134-179, 319-323
+          int best = -1, bestval = d[0] + d[1] + d[2] + d[3] + d[4] + d[5], df = 0;
+#pragma unroll
+          for (int t = 0; t < 5; t++) if (cv[t] > bestval) { bestval = cv[t]; best = t; df = fb[t]; }
+          pass = best >= 0;
+          if (pass && slice_bytes_for_df (df)) ent[nent++] = uint32_t (off) | (uint32_t (best) << 12) | (uint32_t (df) << 16);
+        }
+      }
+    }
+    valid_preamble += __popcll (__ballot (pass));                                       // ref: :326
+    if (pass) atomicOr (&w.vp[off >> 6], 1ull << (off & 63));
+    const int inc = wave_incl_scan (nent, lane);
+    const int tot = __shfl (inc, 63, 64);
+    if (n2 + tot > 1024) { overflow = true; break; }
+    int slot = n2 + inc - nent;
+    for (int k = 0; k < nent; k++) w.q2[slot + k] = ent[k];
+    n2 += tot;
+  }
+  __builtin_amdgcn_s_waitcnt (0xc07f);
+  __builtin_amdgcn_wave_barrier ();
+
+  // ---- stage D: 56/112-bit slicing + CRC, the whole wave on one candidate ----
+  uint32_t nrec = 0;
+  Record *out = p.records + size_t (strip) * p.cap;
+  for (int qi = 0; qi < n2 && !overflow; qi++) {
+    const uint32_t e = __builtin_amdgcn_readfirstlane (w.q2[qi]);   // same entry for the whole wave
+    const int off = e & 0xFFF, t = 4 + int ((e >> 12) & 7), df = int (e >> 16);
+    const int nslice = slice_bytes_for_df (df) * 8;       // 56 or 112
+    const int ncrc = msg_bits_for_df (df);                // bits the score's CRC runs over
+    const uint16_t *m = V + off + 19;
+    u64 bits[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int k = 64 * h + lane;
+      bool one = false;
+      if (k < nslice) {
+        const int f = t + 12 * k;
+        const int i = (f * 0xCCCD) >> 18, r = f - 5 * i;
+        const int a0 = m[i], a1 = m[i + 1], a2 = m[i + 2], a3 = m[i + 3];
+        const int w2 = r < 3 ? 2 + r : 5;
+        const int v = (5 - r) * a0 + (2 * r - 3) * a1 - w2 * a2 - (r == 4 ? a3 : 0);
+        one = v > 0;
+      }
+      bits[h] = __ballot (one);
+    }
+    // syndrome = XOR of the single-bit syndromes of the set bits (the CRC is linear)
+    const int sbo = kLongBits - ncrc;
+    uint32_t x = 0;
+    if (lane < ncrc && ((bits[0] >> lane) & 1)) x ^= w.sb[lane + sbo];
+    if (64 + lane < ncrc && ((bits[1] >> lane) & 1)) x ^= w.sb[64 + lane + sbo];
+    const uint32_t syn = wave_xor (x);
+    const u64 live0 = ncrc >= 64 ? bits[0] : (bits[0] & ((1ull << ncrc) - 1));
+    const u64 live1 = ncrc > 64 ? (bits[1] & ((1ull << (ncrc - 64)) - 1)) : 0;
+    if ((live0 | live1) == 0) continue;                    // all-zero message (ref: src/dump1090.c:3295)
+
+    int cls, nerr = 0, b0 = 0, b1 = 0;
+    if (df == 17 || df == 18 || df == 11) {
+      const uint32_t key = df == 11 ? (syn & 0xFFFF80u) : syn;
+      cls = df == 11 ? kClsDF11 : kClsES;
+      if (key != 0) {
+        const ErrEntry *tab = ncrc == kShortBits ? p.short_tab : p.long_tab;
+        const int tn = ncrc == kShortBits ? p.short_n : p.long_n;
+        const int hit = table_find (tab, tn, key, lane);
+        if (hit < 0) continue;                             // uncorrectable (ref: src/dump1090.c:3315,3343)
+        const ErrEntry te = tab[hit];
+        nerr = te.nerr; b0 = te.bit0; b1 = te.bit1;
+        if (df == 11 && nerr > 1) continue;                // ref: src/dump1090.c:3322
+      }
+    } else
+      cls = (df == 20 || df == 21) ? kClsAP2 : kClsAP;
+
+    if (nrec >= p.cap) { overflow = true; break; }
+    if (lane == 0 && p.write_records) {
+      const uint32_t w0 = rev_in_bytes (uint32_t (bits[0])), w1 = rev_in_bytes (uint32_t (bits[0] >> 32));
+      const uint32_t w2 = rev_in_bytes (uint32_t (bits[1])), w3 = rev_in_bytes (uint32_t (bits[1] >> 32));
+      // Record layout: off,phase,df | cls,nerr,bit0,bit1 | crc | msg[0..13] | flags,pad
+      uint4 lo, hi;
+      lo.x = uint32_t (off) | (uint32_t (t) << 16) | (uint32_t (df) << 24);
+      lo.y = uint32_t (cls) | (uint32_t (uint8_t (nerr)) << 8) | (uint32_t (uint8_t (b0)) << 16) | (uint32_t (uint8_t (b1)) << 24);
+      lo.z = syn;
+      lo.w = w0;
+      hi.x = w1; hi.y = w2; hi.z = w3 & 0xFFFF; hi.w = 0;
+      uint4 *dst = reinterpret_cast<uint4 *> (out + nrec);
+      dst[0] = lo; dst[1] = hi;
+    }
+    nrec++;
+  }
+
+  if (p.vp_bitmap) p.vp_bitmap[size_t (strip) * 64 + lane] = w.vp[lane];
+  if (lane == 0) {
+    p.counts[strip] = overflow ? 0xFFFFFFFFu : nrec;
+    if (valid_preamble) atomicAdd (&p.stats[0], (u64) valid_preamble);
+    if (nrec) atomicAdd (&p.stats[1], (u64) nrec);
+    if (overflow) atomicAdd (&p.stats[2], 1ull);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// stand-alone stateless converters (convert_func on device buffers)
+// ------------------------------------------------------------------------------------------
+template <int CONV>
+__global__ __launch_bounds__ (256)
+void convert_kernel (const uint8_t *iq, uint16_t *mag, size_t n, const uint16_t *lut256, unsigned long long *power_u64)
+{
+  __shared__ uint16_t lut[256];
+  if (CONV == kConvUc8Lut || CONV == kConvUc8LutPower) {
+    lut[threadIdx.x] = lut256[threadIdx.x];
+    __syncthreads ();
+  }
+  u64 power = 0;
+  const size_t stride = size_t (gridDim.x) * blockDim.x;
+  for (size_t i = size_t (blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    uint16_t m;
+    if (CONV == kConvUc8Lut || CONV == kConvUc8LutPower) {
+      m = lut[iq[i]];
+      if (CONV == kConvUc8LutPower) power += uint32_t (m) * uint32_t (m);
+    } else if (CONV == kConvUc8Generic) {
+      m = mag_from_float (c_uc8_float[iq[2 * i]], c_uc8_float[iq[2 * i + 1]], nullptr);
+    } else {
+      const int16_t *s = reinterpret_cast<const int16_t *> (iq) + 2 * i;
+      if (CONV == kConvSc16Int) m = mag_sc16_int (s[0], s[1]);
+      else {
+        const float sc = CONV == kConvSc16Generic ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
+        m = mag_from_float (float (s[0]) * sc, float (s[1]) * sc, nullptr);
+      }
+    }
+    mag[i] = m;
+  }
+  if (CONV == kConvUc8LutPower) {
+    for (int d = 32; d >= 1; d >>= 1) power += __shfl_xor (power, d, 64);
+    if ((threadIdx.x & 63) == 0 && power) atomicAdd (power_u64, power);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// one magnitude of the virtual stream V[x] (x = scan position domain), any converter, slow path
+// ------------------------------------------------------------------------------------------
+template <int CONV>
+__device__ __forceinline__ uint16_t mag_of_V (const uint8_t *iq, uint64_t nsamples, const uint16_t *halo, uint32_t ov,
+                                              uint32_t block_samples, const uint16_t *lut256, long long x)
+{
+  const long long n = x - (long long) ov;
+  if (n < 0) return (halo && x >= 0) ? halo[x] : uint16_t (0);
+  if (uint64_t (n) >= nsamples) return 0;
+  if (CONV == kConvUc8Lut || CONV == kConvUc8LutPower) {
+    const uint64_t blk = uint64_t (n) / block_samples, i = uint64_t (n) % block_samples;
+    return lut256[iq[blk * 2 * block_samples + i]];
+  }
+  if (CONV == kConvUc8Generic) return mag_from_float (c_uc8_float[iq[2 * n]], c_uc8_float[iq[2 * n + 1]], nullptr);
+  const int16_t *s = reinterpret_cast<const int16_t *> (iq) + 2 * n;
+  if (CONV == kConvSc16Int) return mag_sc16_int (s[0], s[1]);
+  const float sc = CONV == kConvSc16Generic ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
+  return mag_from_float (float (s[0]) * sc, float (s[1]) * sc, nullptr);
+}
+
+// Sum of squared magnitudes V[pos[i] + 19 .. + len[i]) for accepted messages
+// (ref: src/demod-2400.c:486-497).  One wave per message.
+template <int CONV>
+__global__ __launch_bounds__ (256)
+void rssi2400_kernel (const uint8_t *iq, uint64_t nsamples, const uint16_t *halo, uint32_t ov, uint32_t block_samples,
+                      const uint16_t *lut256, const uint64_t *pos, const uint32_t *len, uint64_t *sum_out, uint32_t nmsg)
+{
+  const uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= nmsg) return;
+  const long long base = (long long) pos[i] + 19;
+  const int n = int (len[i]);
+  u64 acc = 0;
+  for (int k = lane; k < n; k += 64) {
+    const uint32_t m = mag_of_V<CONV> (iq, nsamples, halo, ov, block_samples, lut256, base + k);
+    acc += u64 (m * m);
+  }
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor (acc, d, 64);
+  if (lane == 0) sum_out[i] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// exclusive scan of the per-strip record counts (overflowed strips count as 0) + gather
+// ------------------------------------------------------------------------------------------
+constexpr int kScanChunk = 1024;
+
+__device__ __forceinline__ uint32_t clean_count (uint32_t c) { return c == 0xFFFFFFFFu ? 0u : c; }
+
+__global__ __launch_bounds__ (256)
+void chunk_sums_kernel (const uint32_t *counts, uint32_t n, uint64_t *chunk_sum)
+{
+  __shared__ uint32_t part[4];
+  const uint32_t base = blockIdx.x * kScanChunk;
+  uint32_t s = 0;
+  for (uint32_t i = threadIdx.x; i < kScanChunk; i += 256) if (base + i < n) s += clean_count (counts[base + i]);
+  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor (int (s), d, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads ();
+  if (threadIdx.x == 0) chunk_sum[blockIdx.x] = u64 (part[0]) + part[1] + part[2] + part[3];
+}
+
+// single workgroup: exclusive scan of chunk sums in place; total goes to chunk_sum[nchunks]
+__global__ __launch_bounds__ (1024)
+void scan_chunk_sums_kernel (uint64_t *chunk_sum, uint32_t nchunks)
+{
+  __shared__ uint64_t buf[1024];
+  __shared__ uint64_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads ();
+  for (uint32_t base = 0; base < nchunks; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    const uint64_t v = i < nchunks ? chunk_sum[i] : 0;
+    buf[threadIdx.x] = v;
+    __syncthreads ();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const uint64_t o = threadIdx.x >= (unsigned) d ? buf[threadIdx.x - d] : 0;
+      __syncthreads ();
+      buf[threadIdx.x] += o;
+      __syncthreads ();
+    }
+    if (i < nchunks) chunk_sum[i] = carry + buf[threadIdx.x] - v;
+    __syncthreads ();
+    if (threadIdx.x == 1023) carry += buf[1023];
+    __syncthreads ();
+  }
+  if (threadIdx.x == 0) chunk_sum[nchunks] = carry;
+}
+
+// one wave per strip: offsets[strip] = chunk base + scan inside the chunk; copies the strip's records
+__global__ __launch_bounds__ (256)
+void gather_kernel (const uint32_t *counts, uint32_t nstrips, const uint64_t *chunk_sum, const Record *records,
+                    uint32_t cap, Record *packed, uint64_t *packed_pos, uint64_t *offsets)
+{
+  const uint32_t strip = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (strip >= nstrips) return;
+  const uint32_t chunk = strip / kScanChunk, first = chunk * kScanChunk;
+  uint64_t before = 0;
+  for (uint32_t i = first + lane; i < strip; i += 64) before += clean_count (counts[i]);
+  for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor (before, d, 64);
+  const uint64_t off = chunk_sum[chunk] + before;
+  const uint32_t cnt = clean_count (counts[strip]);
+  if (lane == 0) offsets[strip] = off;
+  const uint4 *src = reinterpret_cast<const uint4 *> (records + size_t (strip) * cap);
+  uint4 *dst = reinterpret_cast<uint4 *> (packed + off);
+  for (uint32_t i = lane; i < cnt * 2; i += 64) dst[i] = src[i];
+  for (uint32_t i = lane; i < cnt; i += 64) packed_pos[off + i] = uint64_t (strip) * kStrip + records[size_t (strip) * cap + i].off;
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers (called from engine.cpp)
+// ------------------------------------------------------------------------------------------
+hipError_t upload_constants (const uint32_t *single_bit, const float *uc8_float)
+{
+  hipError_t e = hipMemcpyToSymbol (HIP_SYMBOL (c_single_bit), single_bit, sizeof (uint32_t) * kLongBits);
+  if (e != hipSuccess) return e;
+  return hipMemcpyToSymbol (HIP_SYMBOL (c_uc8_float), uc8_float, sizeof (float) * 256);
+}
+
+hipError_t launch_scan2400 (const ScanParams &p, hipStream_t stream)
+{
+  const dim3 grid ((p.nstrips + kWavesPerBlock - 1) / kWavesPerBlock), block (64 * kWavesPerBlock);
+  if (p.nstrips == 0) return hipSuccess;
+  switch (p.conv) {
+    case kConvUc8Lut: case kConvUc8LutPower:
+      hipLaunchKernelGGL (scan2400_kernel<kConvUc8Lut>, grid, block, 0, stream, p); break;
+    case kConvUc8Generic:     hipLaunchKernelGGL (scan2400_kernel<kConvUc8Generic>, grid, block, 0, stream, p); break;
+    case kConvSc16Int:        hipLaunchKernelGGL (scan2400_kernel<kConvSc16Int>, grid, block, 0, stream, p); break;
+    case kConvSc16Generic:    hipLaunchKernelGGL (scan2400_kernel<kConvSc16Generic>, grid, block, 0, stream, p); break;
+    case kConvSc16Q11Generic: hipLaunchKernelGGL (scan2400_kernel<kConvSc16Q11Generic>, grid, block, 0, stream, p); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError ();
+}
+
+hipError_t launch_convert (int conv, const uint8_t *iq, uint16_t *mag, size_t n, const uint16_t *lut256,
+                           unsigned long long *power_u64, hipStream_t stream)
+{
+  if (n == 0) return hipSuccess;
+  const size_t want = (n + 255) / 256;
+  const dim3 grid ((unsigned) (want < 65536 ? want : 65536)), block (256);
+  switch (conv) {
+    case kConvUc8Lut:         hipLaunchKernelGGL (convert_kernel<kConvUc8Lut>, grid, block, 0, stream, iq, mag, n, lut256, power_u64); break;
+    case kConvUc8LutPower:    hipLaunchKernelGGL (convert_kernel<kConvUc8LutPower>, grid, block, 0, stream, iq, mag, n, lut256, power_u64); break;
+    case kConvUc8Generic:     hipLaunchKernelGGL (convert_kernel<kConvUc8Generic>, grid, block, 0, stream, iq, mag, n, lut256, power_u64); break;
+    case kConvSc16Int:        hipLaunchKernelGGL (convert_kernel<kConvSc16Int>, grid, block, 0, stream, iq, mag, n, lut256, power_u64); break;
+    case kConvSc16Generic:    hipLaunchKernelGGL (convert_kernel<kConvSc16Generic>, grid, block, 0, stream, iq, mag, n, lut256, power_u64); break;
+    case kConvSc16Q11Generic: hipLaunchKernelGGL (convert_kernel<kConvSc16Q11Generic>, grid, block, 0, stream, iq, mag, n, lut256, power_u64); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError ();
+}
+
+
+hipError_t launch_rssi2400 (int conv, const uint8_t *iq, uint64_t nsamples, const uint16_t *halo, uint32_t ov,
+                            uint32_t block_samples, const uint16_t *lut256, const uint64_t *pos, const uint32_t *len,
+                            uint64_t *sum_out, uint32_t nmsg, hipStream_t stream)
+{
+  if (nmsg == 0) return hipSuccess;
+  const dim3 grid ((nmsg + 3) / 4), block (256);
+#define RSSI(C) hipLaunchKernelGGL (rssi2400_kernel<C>, grid, block, 0, stream, iq, nsamples, halo, ov, block_samples, lut256, pos, len, sum_out, nmsg)
+  switch (conv) {
+    case kConvUc8Lut: case kConvUc8LutPower: RSSI (kConvUc8Lut); break;
+    case kConvUc8Generic:     RSSI (kConvUc8Generic); break;
+    case kConvSc16Int:        RSSI (kConvSc16Int); break;
+    case kConvSc16Generic:    RSSI (kConvSc16Generic); break;
+    case kConvSc16Q11Generic: RSSI (kConvSc16Q11Generic); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef RSSI
+  return hipGetLastError ();
+}
+
+// counts[nstrips] -> offsets[nstrips], packed records/positions; chunk_sum needs nstrips/1024 + 2 entries.
+// The grand total is left in chunk_sum[nchunks].
+hipError_t launch_compact (const uint32_t *counts, uint32_t nstrips, uint64_t *chunk_sum, const Record *records,
+                           uint32_t cap, Record *packed, uint64_t *packed_pos, uint64_t *offsets, hipStream_t stream)
+{
+  if (nstrips == 0) return hipSuccess;
+  const uint32_t nchunks = (nstrips + kScanChunk - 1) / kScanChunk;
+  hipLaunchKernelGGL (chunk_sums_kernel, dim3 (nchunks), dim3 (256), 0, stream, counts, nstrips, chunk_sum);
+  hipLaunchKernelGGL (scan_chunk_sums_kernel, dim3 (1), dim3 (1024), 0, stream, chunk_sum, nchunks);
+  if (packed)
+    hipLaunchKernelGGL (gather_kernel, dim3 ((nstrips + 3) / 4), dim3 (256), 0, stream, counts, nstrips, chunk_sum, records,
+                        cap, packed, packed_pos, offsets);
+  return hipGetLastError ();
+}
+
+}  // namespace modes

@@ -1,0 +1,118 @@
+"""Synthetic Mode S captures: complex baseband, OOK pulses box-integrated over
+each sample period, random sub-sample phase, carrier phase and amplitude, AWGN, quantised to
+uc8 or sc16.  Used by the tests and by bench.py; no reference code involved.
+"""
+import numpy as np
+
+_POLY = 0xFFF409
+
+
+def crc24(data: bytes) -> int:
+    """Mode S parity over `data` (the message without its last three bytes)."""
+    rem = 0
+    for b in data:
+        rem ^= b << 16
+        for _ in range(8):
+            rem = ((rem << 1) ^ _POLY) if rem & 0x800000 else (rem << 1)
+        rem &= 0xFFFFFF
+    return rem
+
+
+def make_df17(icao: int, me: bytes, ca: int = 5) -> bytes:
+    body = bytes([(17 << 3) | ca, (icao >> 16) & 0xFF, (icao >> 8) & 0xFF, icao & 0xFF]) + bytes(me[:7]).ljust(7, b"\0")
+    p = crc24(body)
+    return body + bytes([(p >> 16) & 0xFF, (p >> 8) & 0xFF, p & 0xFF])
+
+
+def make_df11(icao: int, ca: int = 5, iid: int = 0) -> bytes:
+    body = bytes([(11 << 3) | ca, (icao >> 16) & 0xFF, (icao >> 8) & 0xFF, icao & 0xFF])
+    p = crc24(body) ^ iid
+    return body + bytes([(p >> 16) & 0xFF, (p >> 8) & 0xFF, p & 0xFF])
+
+
+def make_ap(df: int, icao: int, payload: bytes) -> bytes:
+    """Address/Parity formats (DF0/4/5 short, DF16/20/21 long): parity = CRC xor address."""
+    n = 11 if df in (16, 20, 21) else 4
+    body = bytes([(df << 3) | (payload[0] & 7)]) + bytes(payload[1:n]).ljust(n - 1, b"\0")
+    p = crc24(body) ^ icao
+    return body + bytes([(p >> 16) & 0xFF, (p >> 8) & 0xFF, p & 0xFF])
+
+
+def chips_of(msg: bytes) -> np.ndarray:
+    """0.5 us chips: 8 us preamble (pulses at 0, 1, 3.5, 4.5 us) then Manchester bits (1 = on,off)."""
+    pre = np.zeros(16, dtype=np.float64)
+    pre[[0, 2, 7, 9]] = 1.0
+    bits = np.unpackbits(np.frombuffer(msg, dtype=np.uint8))
+    data = np.empty(2 * len(bits), dtype=np.float64)
+    data[0::2] = bits
+    data[1::2] = 1 - bits
+    return np.concatenate([pre, data])
+
+
+def envelope(msg: bytes, sample_rate: float, frac: float) -> np.ndarray:
+    """Per-sample mean of the on/off envelope; the frame starts `frac` samples (0..1) into sample 0."""
+    ch = chips_of(msg)
+    cps = sample_rate * 0.5e-6                      # samples per chip
+    edges = frac + cps * np.arange(len(ch) + 1)     # chip boundaries in sample units
+    cum = np.concatenate([[0.0], np.cumsum(ch) * cps])
+    n = int(np.ceil(edges[-1])) + 1
+    t = np.arange(n + 1, dtype=np.float64)
+    integ = np.interp(t, edges, cum, left=0.0, right=cum[-1])
+    return np.diff(integ)
+
+
+def quantise(x: np.ndarray, fmt: str) -> np.ndarray:
+    """x: complex array, full scale 1.0.  Returns interleaved I,Q in uc8 (uint8) or sc16 (int16)."""
+    iq = np.empty(2 * len(x), dtype=np.float64)
+    iq[0::2] = x.real
+    iq[1::2] = x.imag
+    if fmt == "uc8":
+        return np.clip(np.round(iq * 127.5 + 127.5), 0, 255).astype(np.uint8)
+    if fmt == "sc16":
+        return np.clip(np.round(iq * 32767.0), -32768, 32767).astype(np.int16)
+    if fmt == "sc16q11":
+        return np.clip(np.round(iq * 2047.0), -2048, 2047).astype(np.int16)
+    raise ValueError(fmt)
+
+
+def capture(nsamples: int, sample_rate: float = 2.4e6, fmt: str = "uc8", seed: int = 1, frames_per_sec: float = 1000.0,
+            n_icao: int = 16, noise_sigma: float = 0.01, overlap_fraction: float = 0.1, bitflip1: float = 0.0,
+            bitflip2: float = 0.0, dc_offset: complex = 0.0, ap_fraction: float = 0.0, min_amp_db: float = -32.0,
+            max_amp_db: float = -4.0):
+    """Returns (iq array, list of injected frames as dicts {start, msg (as sent), clean (before bit flips), amp})."""
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal(nsamples) + 1j * rng.standard_normal(nsamples)) * noise_sigma + dc_offset
+    icaos = rng.integers(0x400000, 0x4FFFFF, size=n_icao)
+    nframes = int(frames_per_sec * nsamples / sample_rate)
+    frames = []
+    gap = int(150e-6 * sample_rate)
+    pos = rng.integers(0, gap)
+    mean_step = nsamples / max(nframes, 1)
+    for _ in range(nframes):
+        kind = rng.random()
+        icao = int(icaos[rng.integers(0, n_icao)])
+        if kind < ap_fraction:
+            df = int(rng.choice([0, 4, 5, 16, 20, 21]))
+            clean = make_ap(df, icao, bytes(rng.integers(0, 256, size=11, dtype=np.uint8)))
+        elif kind < ap_fraction + (1 - ap_fraction) * 0.6:
+            clean = make_df17(icao, bytes(rng.integers(0, 256, size=7, dtype=np.uint8)))
+        else:
+            clean = make_df11(icao)
+        msg = bytearray(clean)
+        r = rng.random()
+        nflip = 2 if r < bitflip2 else 1 if r < bitflip2 + bitflip1 else 0
+        for b in rng.choice(np.arange(5, 8 * len(msg)), size=nflip, replace=False):
+            msg[b >> 3] ^= 0x80 >> (b & 7)
+        amp = 10 ** (rng.uniform(min_amp_db, max_amp_db) / 20.0)
+        env = envelope(bytes(msg), sample_rate, rng.random())
+        if pos + len(env) >= nsamples:
+            break
+        ph = np.exp(2j * np.pi * rng.random())
+        x[pos:pos + len(env)] += amp * ph * env
+        frames.append({"start": int(pos), "msg": bytes(msg), "clean": bytes(clean), "amp": float(amp), "nflip": nflip})
+        if rng.random() < overlap_fraction:                       # an overlapping straggler
+            step = int(rng.integers(20, len(env)))
+        else:
+            step = len(env) + gap + int(rng.exponential(max(mean_step - len(env) - gap, 1.0)))
+        pos += step
+    return quantise(x, fmt), frames

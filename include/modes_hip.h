@@ -1,0 +1,235 @@
+/*
+ * modes_hip.h -- C ABI of libmodes_hip.so, the MI355X (gfx950) engine for the raw-IQ hot
+ * path of gvanem/Dump1090:  IQ -> uint16 magnitude -> Mode S / Mode A/C demodulation ->
+ * CRC-24 syndrome + 1/2-bit repair.
+ *
+ * Part 1 are the reference's own entry points for this path, same names, same signatures,
+ * same struct layouts, so the reference can link this library instead of convert.c,
+ * demod-*.c and crc.c.  Part 2 is the one extra call a drop-in host
+ * makes to hand over the callbacks the reference's demodulators reach into.  Part 3 is the
+ * bulk API: whole recordings resident in HBM, block geometry of `bin_read` reproduced on
+ * the device, one ordered message list out.
+ *
+ * Plain C, plain pointers and sizes.  "ref:" = file:line under the reference's root.
+ */
+#ifndef MODES_HIP_H
+#define MODES_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include <stdbool.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ===================================================================================== */
+/* Part 1 -- the reference's interface for this path                                      */
+/* ===================================================================================== */
+
+/* ref: src/convert.h:12-19 */
+typedef struct convert_state {
+  float       DC_A;
+  float       DC_B;
+  float       z1_I;
+  float       z1_Q;
+  const char *func_name;
+  const char *description;
+} convert_state;
+
+/* ref: src/convert.h:21-26 */
+typedef enum convert_format {
+  INPUT_ILLEGAL = 0,
+  INPUT_UC8,
+  INPUT_SC16,
+  INPUT_SC16Q11
+} convert_format;
+
+/* ref: src/convert.h:28-32 */
+typedef void (*convert_func) (const void *iq_input, uint16_t *mag_output, unsigned nsamples,
+                              convert_state *state, double *out_power);
+
+/* ref: src/convert.h:34-38, src/convert.c:310-365.  Returns NULL when no converter in the
+ * table supports (format, filter_dc, compute_power). */
+convert_func convert_init (convert_format format, double sample_rate, bool filter_dc,
+                           bool compute_power, convert_state **state_p);
+/* ref: src/convert.h:40, src/convert.c:375-381 */
+const char  *convert_format_name (convert_format f);
+/* ref: src/convert.h:42, src/convert.c:367-373 */
+void         convert_cleanup (convert_state **state_p);
+
+/* ref: src/fifo.h:15-18 */
+typedef enum mag_buf_flags { MAGBUF_ZERO = 0, MAGBUF_DISCONTINUOUS = 1 } mag_buf_flags;
+
+/* ref: src/fifo.h:50-63 (u_int == unsigned int) */
+typedef struct mag_buf {
+  uint16_t       *data;
+  unsigned        total_length;
+  unsigned        valid_length;
+  unsigned        overlap;
+  uint64_t        sample_timestamp;
+  uint64_t        sys_timestamp;
+  mag_buf_flags   flags;
+  double          mean_level;
+  double          mean_power;
+  unsigned        dropped;
+  struct mag_buf *next;
+} mag_buf;
+
+/* ref: src/demod.h:7-12.  Synchronous: every callback of a block has fired on return. */
+void demod_2000 (const mag_buf *mag);
+void demod_2400 (const mag_buf *mag);
+void demod_2400_AC (const mag_buf *mag);
+void demod_8000 (const mag_buf *mag);
+int  demod_8000_alloc (void);      /* non-zero = ok */
+void demod_8000_free (void);
+
+/* ref: src/crc.h:11-23 */
+#define MODES_MAX_BITERRORS 2
+typedef struct errorinfo {
+  uint32_t syndrome;
+  int      errors;
+  int8_t   bit [MODES_MAX_BITERRORS];
+} errorinfo;
+
+void       crc_init (int fix_bits);
+void       crc_exit (void);
+uint32_t   crc_checksum (const uint8_t *msg, int bitlen);
+errorinfo *crc_checksum_diagnose (uint32_t syndrome, int bitlen);
+void       crc_checksum_fix (uint8_t *msg, const errorinfo *info);
+
+/* ===================================================================================== */
+/* Part 2 -- binding a drop-in host                                                       */
+/* ===================================================================================== */
+
+/* The reference's demodulators call back into dump1090.c (ref: src/misc.h:866-871,900) and
+ * read a few `Modes` fields (ref: src/misc.h:496-642).  A host hands them over once.
+ * `modeS_message` is opaque to the library: it is told the size and the offsets of the
+ * members the demodulators themselves touch (ref: src/misc.h:721-806).
+ * Any callback left NULL is served by the library's own implementation of the same rule
+ * (score / accept / ICAO cache of ref: src/dump1090.c:1438-1476,2372-2720,3279-3365), and
+ * accepted messages are then queued for modes_hip_take_messages(). */
+typedef struct modes_hip_host {
+  size_t   mm_size;                 /* sizeof(modeS_message)                    */
+  size_t   off_timestamp_msg;       /* offsetof(modeS_message, timestamp_msg)   */
+  size_t   off_sys_timestamp_msg;
+  size_t   off_sig_level;           /* double                                   */
+  size_t   off_score;               /* int                                      */
+  size_t   off_error_bits;          /* int                                      */
+  size_t   off_AC_flags;            /* uint32_t                                 */
+  size_t   off_addr;                /* uint32_t                                 */
+  int      (*modeS_message_score) (const uint8_t *msg, int valid_bits);
+  int      (*decode_mode_S_message) (void *mm, const uint8_t *msg);
+  void     (*decode_mode_A_message) (void *mm, int mode_A);
+  void     (*modeS_user_message) (void *mm);
+  int      (*modeS_message_len_by_type) (int type);
+  int64_t  (*receiveclock_ms_elapsed) (uint64_t t1, uint64_t t2);
+  int      phase_enhance;           /* Modes.phase_enhance  */
+  int      mode_AC;                 /* Modes.mode_AC        */
+  int      measure_noise;           /* Modes.measure_noise  */
+  int      fix_bits;                /* error_correct_1 + error_correct_2, used when crc_init was not called */
+  int      device;                  /* HIP device ordinal   */
+} modes_hip_host;
+
+/* Returns 0, or a negative modes_status.  Passing NULL restores the built-in defaults. */
+int modes_hip_bind (const modes_hip_host *host);
+
+/* ===================================================================================== */
+/* Part 3 -- bulk engine                                                                  */
+/* ===================================================================================== */
+
+typedef enum modes_status {
+  MODES_OK = 0,
+  MODES_E_ARG = -1,          /* bad argument / unsupported combination      */
+  MODES_E_NODEVICE = -2,     /* no usable HIP device                        */
+  MODES_E_HIP = -3,          /* a HIP call failed; see modes_last_error()   */
+  MODES_E_NOMEM = -4,
+  MODES_E_OVERFLOW = -5      /* a fixed-capacity device buffer overflowed   */
+} modes_status;
+
+const char *modes_last_error (void);
+
+/* One accepted message, in the order modeS_user_message() would have seen it. */
+typedef struct modes_message {
+  uint64_t timestamp;        /* mm.timestamp_msg, 12 MHz                           */
+  uint8_t  msg[14];          /* after CRC repair; msg_bits/8 bytes are meaningful   */
+  uint8_t  msg_bits;         /* 56 / 112 (16 for Mode A/C)                          */
+  uint8_t  msg_type;         /* DF, 24 for DF24..31, 32 for Mode A/C                */
+  uint32_t addr;             /* mm.addr incl. the non-ICAO flag bit 24              */
+  uint32_t crc;              /* syndrome before repair (mm.CRC)                     */
+  int16_t  score;            /* score that selected the message, -1 where n/a       */
+  uint8_t  error_bits;
+  uint8_t  phase;            /* demod_2400: phase 4..8; demod_2000: 1 = phase-corrected retry */
+  uint32_t block;            /* index of the 256 KiB block (bin_read call)          */
+  double   sig_level;        /* mm.sig_level                                        */
+  uint32_t j;                /* sample offset inside the block's mag_buf            */
+  uint32_t reserved;
+} modes_message;             /* 56 bytes */
+
+typedef struct modes_stats {
+  uint64_t valid_preamble, demodulated, out_of_phase, demod_modeac;
+  uint64_t CRC_good, CRC_bad, CRC_fixed, CRC_single_bit_fix, CRC_two_bits_fix;
+  uint64_t demod_rejected_unknown;
+  uint64_t candidates;       /* records that left the scan kernel               */
+  uint64_t replay_rounds;    /* fixed-point rounds of the device replay          */
+} modes_stats;
+
+typedef struct modes_engine_config {
+  uint32_t sample_rate;      /* 2000000 / 2400000 / 8000000 (ref: src/dump1090.c:702-732) */
+  int32_t  input_format;     /* convert_format                                              */
+  int32_t  filter_dc;        /* as convert_init()                                           */
+  int32_t  compute_power;    /* as convert_init() (Modes.measure_noise)                     */
+  int32_t  fix_bits;         /* error_correct_1 + error_correct_2 (ref: src/dump1090.c:964) */
+  int32_t  phase_enhance;
+  int32_t  mode_ac;          /* run demod_2400_AC after demod_2400 / detect_mode_A in demod_2000 */
+  int32_t  device;           /* HIP device ordinal                                          */
+  int32_t  host_replay;      /* 1 = do the ordered accept pass on the host (debug/compare)  */
+  int32_t  reserved[7];
+} modes_engine_config;
+
+typedef struct modes_engine modes_engine;
+
+int  modes_engine_create (const modes_engine_config *cfg, modes_engine **out);
+void modes_engine_destroy (modes_engine *e);
+
+/* Seed / read the 1024-slot ICAO cache (ref: src/dump1090.c:1438-1476): one address per slot,
+ * 0 = empty.  Used to chain shards of one recording across GPUs. */
+int  modes_engine_set_icao (modes_engine *e, const uint32_t *slots1024);
+int  modes_engine_get_icao (modes_engine *e, uint32_t *slots1024);
+
+/* Decode `nbytes` of IQ that are ALREADY in device memory (d_iq), exactly as
+ * `dump1090 --infile` would (ref: src/infile.c:116-197): 256 KiB blocks, overlap carried
+ * from block to block, the stream's first block preceded by zeros.
+ *   first_sample : Modes.sample_counter at d_iq[0] (multiple of the block length)
+ *   d_halo       : device pointer to the `overlap` magnitudes that precede d_iq[0] (the tail a
+ *                  previous shard produced), or NULL for zeros
+ *   stream       : hipStream_t to run on (NULL = the default stream)
+ * Results stay in the engine until the next run. */
+int  modes_engine_run_device (modes_engine *e, const void *d_iq, size_t nbytes,
+                              uint64_t first_sample, const uint16_t *d_halo, void *stream);
+/* Same, input in host memory (copied with hipMemcpyAsync first). */
+int  modes_engine_run_host (modes_engine *e, const void *iq, size_t nbytes, uint64_t first_sample);
+
+/* Only the scan (convert + detect + slice + CRC) kernel of the last configuration, `reps`
+ * times on `stream`, bracketed by HIP events on that stream.  ms_out receives the average
+ * kernel duration.  For roofline measurements. */
+int  modes_engine_time_scan (modes_engine *e, const void *d_iq, size_t nbytes, int reps, void *stream, float *ms_out);
+
+size_t               modes_engine_num_messages (const modes_engine *e);
+const modes_message *modes_engine_messages (const modes_engine *e);      /* host memory */
+int                  modes_engine_get_stats (const modes_engine *e, modes_stats *out);
+/* the last block's trailing `overlap` magnitudes (device memory), to pass as d_halo of the next shard */
+const uint16_t      *modes_engine_tail_halo (const modes_engine *e);
+
+/* Stand-alone converter on device buffers: what convert_func computes, for n samples. */
+int  modes_convert_device (int converter_id /* row of converters_table, ref: src/convert.c:301-308 */,
+                           const void *d_iq, uint16_t *d_mag, size_t nsamples,
+                           convert_state *state, double *out_power, void *stream);
+
+/* messages queued by the drop-in demod_*() when no modeS_user_message callback is bound */
+size_t modes_hip_take_messages (modes_message *out, size_t max);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

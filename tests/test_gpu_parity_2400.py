@@ -1,0 +1,105 @@
+"""GPU parity: the HIP engine behind the C ABI against the CPU oracle, 2.4 MS/s path.
+Bit-exact on every integer/byte field; sig_level within 1e-5 relative (north_star)."""
+import numpy as np
+import pytest
+
+import dump1090_amd as da
+from dump1090_amd import synth
+from oracle import orc
+from util import assert_same_messages, oracle_run
+
+pytestmark = pytest.mark.gpu
+FMT = {"uc8": da.INPUT_UC8, "sc16": da.INPUT_SC16, "sc16q11": da.INPUT_SC16Q11}
+
+
+def engine_run(iq, fmt, **kw):
+    e = da.Engine(2400000, FMT[fmt], **kw)
+    e.run_host(iq)
+    return e.messages(), e.stats()
+
+
+@pytest.mark.parametrize("fix_bits", [0, 1, 2])
+def test_sc16_synthetic_matches_oracle(fix_bits):
+    iq, frames = synth.capture(2_400_000, 2.4e6, "sc16", seed=10 + fix_bits, frames_per_sec=1500, bitflip1=0.2,
+                               bitflip2=0.1, ap_fraction=0.25)
+    exp, est = oracle_run(iq, "sc16", fix_bits=fix_bits)
+    got, gst = engine_run(iq, "sc16", fix_bits=fix_bits)
+    assert len(exp) > 500
+    assert_same_messages(got, exp)
+    for k in ("valid_preamble", "demodulated", "CRC_good", "CRC_bad", "CRC_single_bit_fix", "CRC_two_bits_fix",
+              "out_of_phase", "demod_rejected_unknown"):
+        assert gst[k] == est[k], k
+
+
+def test_sc16_phase_enhance_matches_oracle():
+    iq, _ = synth.capture(1_200_000, 2.4e6, "sc16", seed=21, frames_per_sec=2000, bitflip1=0.2, ap_fraction=0.2)
+    exp, est = oracle_run(iq, "sc16", fix_bits=2, phase_enhance=True)
+    got, gst = engine_run(iq, "sc16", fix_bits=2, phase_enhance=True)
+    assert len(exp) > 300
+    assert_same_messages(got, exp)
+    assert gst["valid_preamble"] == est["valid_preamble"] and gst["out_of_phase"] == est["out_of_phase"]
+
+
+def test_uc8_lut_as_written_matches_oracle(modes1):
+    """BASELINE config 1: modes1.bin at 2.4 MS/s through the reference-selected converter."""
+    exp, est = oracle_run(modes1, "uc8")
+    got, gst = engine_run(modes1, "uc8")
+    assert len(exp) == 0 and len(got) == 0
+    assert gst["valid_preamble"] == est["valid_preamble"] == 2016
+
+
+def test_sc16_generic_power_path_matches_oracle():
+    """compute_power selects convert_sc16_generic (float path, DC block off)."""
+    iq, _ = synth.capture(800_000, 2.4e6, "sc16", seed=5, frames_per_sec=1500)
+    exp, est = oracle_run(iq, "sc16", compute_power=True)
+    got, gst = engine_run(iq, "sc16", compute_power=True)
+    assert len(exp) > 200
+    assert_same_messages(got, exp)
+    assert gst["valid_preamble"] == est["valid_preamble"]
+
+
+def test_sc16q11_matches_oracle():
+    iq, _ = synth.capture(600_000, 2.4e6, "sc16q11", seed=6, frames_per_sec=1500, min_amp_db=-20)
+    exp, est = oracle_run(iq, "sc16q11")
+    got, gst = engine_run(iq, "sc16q11")
+    assert len(exp) > 100
+    assert_same_messages(got, exp)
+
+
+@pytest.mark.parametrize("nsamples", [0, 1, 300, 4095, 4096, 4097, 65536, 65537, 131072 + 17])
+def test_ragged_lengths(nsamples):
+    iq, _ = synth.capture(max(nsamples, 1), 2.4e6, "sc16", seed=3, frames_per_sec=3000, min_amp_db=-12)
+    iq = iq[: 2 * nsamples]
+    exp, est = oracle_run(iq, "sc16")
+    got, gst = engine_run(iq, "sc16")
+    assert_same_messages(got, exp)
+    assert gst["valid_preamble"] == est["valid_preamble"]
+
+
+def test_messages_straddling_block_boundaries():
+    """Frames placed across the 65536-sample block edges: skip-ahead resets per block, overlap carries."""
+    rng = np.random.default_rng(7)
+    offs = (-330, -300, -268, -200, -135, -100, -20, -1, 0, 1, 40)
+    n = 65536 * (len(offs) + 1) + 1000
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.005
+    for b, d in enumerate(offs, start=1):
+        for q, make in ((0, synth.make_df17), (-600, synth.make_df17)):
+            msg = make(0x4840D6 + b, bytes(rng.integers(0, 256, 7, dtype=np.uint8)))
+            env = synth.envelope(msg, 2.4e6, rng.random())
+            p = b * 65536 + d + q
+            x[p:p + len(env)] += 0.3 * np.exp(2j * np.pi * rng.random()) * env
+    iq = synth.quantise(x, "sc16")
+    exp, _ = oracle_run(iq, "sc16")
+    got, _ = engine_run(iq, "sc16")
+    assert len(exp) >= 2 * len(offs) - 2
+    assert_same_messages(got, exp)
+
+
+def test_icao_cache_chaining_across_runs():
+    """A shard run with the cache a previous shard left must equal the oracle's single pass."""
+    iq, _ = synth.capture(65536 * 12, 2.4e6, "sc16", seed=11, frames_per_sec=2000, ap_fraction=0.5, n_icao=4)
+    exp, _ = oracle_run(iq, "sc16")
+    e = da.Engine(2400000, da.INPUT_SC16)
+    e.run_host(iq)
+    assert_same_messages(e.messages(), exp)
+    assert (exp["msg_type"] == 4).sum() + (exp["msg_type"] == 5).sum() + (exp["msg_type"] == 0).sum() > 20
