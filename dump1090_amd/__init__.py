@@ -71,6 +71,12 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ModesError("%s is missing: run `make -C dump1090_amd/csrc` (or __graft_entry__.build())" % LIB_PATH)
+        # One HIP runtime per process: if PyTorch is around, let it load its bundled libamdhip64 first so
+        # that this library binds to the same one (device pointers are then shared with torch tensors).
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = C.CDLL(LIB_PATH)
         L.modes_last_error.restype = C.c_char_p
         L.modes_engine_create.argtypes = [C.POINTER(EngineConfig), C.POINTER(C.c_void_p)]

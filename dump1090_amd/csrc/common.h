@@ -17,7 +17,10 @@ enum Conv : int {
 
 // ---- scan kernel geometry (2.4 MS/s) -------------------------------------------------
 // One wavefront owns one strip of kStrip consecutive scan positions of the stream.
-constexpr int kStrip = 4096;
+constexpr int kStrip = 2048;
+constexpr int kWords = kStrip / 64;   // 64-position words per strip, one per lane
+constexpr int kQ1Cap = 1024;          // stage-B candidates per strip (50 % of the positions)
+constexpr int kQ2Cap = 256;           // stage-C survivors per strip
 constexpr int kLook2400 = 320;     // samples a position may look ahead (<= 290 needed; ref: src/demod-2400.c:339-412,488-494)
 constexpr int kTilePad = 16;       // slack so global loads can start 16-sample aligned
 
@@ -58,13 +61,15 @@ struct ScanParams {
   int32_t         phase_enhance;
   const ErrEntry *short_tab;  int32_t short_n;
   const ErrEntry *long_tab;   int32_t long_n;
+  const uint32_t *bloom_short, *bloom_long;   // 65536-bit filters over the table syndromes
   const uint16_t *lut256;      // as-written uc8 table: mag_lut[byte] (ref: src/convert.c:29)
   Record         *records;     // [nstrips][cap]
   uint32_t       *counts;      // [nstrips]
   uint32_t        cap;
   uint32_t        nstrips;
-  unsigned long long *stats;   // [0] valid_preamble  [1] records  [2] overflow strips
+  uint32_t       *vp_counts;   // [nstrips] positions that reached scoring (Modes.stat.valid_preamble before skip-ahead)
   int32_t         write_records;   // 0 = timing variant that keeps everything but the final store
+  int32_t         debug_stop;      // profiling aid: 1..3 = leave after stage A/B/C (results are then meaningless)
   uint64_t       *vp_bitmap;       // [nstrips][64]: bit = position reached scoring (Modes.stat.valid_preamble), or nullptr
 };
 

@@ -47,6 +47,7 @@ struct DeviceTables {
   ErrEntry *short_tab = nullptr, *long_tab = nullptr;
   int short_n = 0, long_n = 0;
   uint16_t *lut256 = nullptr;
+  uint32_t *bloom_short = nullptr, *bloom_long = nullptr;
 };
 
 template <typename T>
@@ -100,8 +101,8 @@ struct modes_engine {
   IcaoCache cache;
   // device buffers
   DevBuf<Record> records, packed;
-  DevBuf<uint32_t> counts, rssi_len;
-  DevBuf<uint64_t> chunk_sum, packed_pos, offsets, rssi_pos, rssi_sum, vp_bitmap;
+  DevBuf<uint32_t> counts, vp_counts, rssi_len;
+  DevBuf<uint64_t> chunk_sum, chunk_vp, chunk_ovf, packed_pos, offsets, rssi_pos, rssi_sum, vp_bitmap;
   DevBuf<uint8_t> staging;                  // for run_host
   DevBuf<uint16_t> tail;
   unsigned long long *d_stats = nullptr;
@@ -132,8 +133,13 @@ int setup_tables (modes_engine *e)
       HIP_TRY (hipMalloc (reinterpret_cast<void **> (&p), d.size () * sizeof (ErrEntry)));
       HIP_TRY (hipMemcpy (p, d.data (), d.size () * sizeof (ErrEntry), hipMemcpyHostToDevice));
     }
-    if (bits == kShortBits) { t.short_tab = p; t.short_n = int (d.size ()); }
-    else                    { t.long_tab = p;  t.long_n = int (d.size ()); }
+    std::vector<uint32_t> bloom (2048, 0);
+    for (const ErrEntry &x : d) { const uint32_t h = (x.syndrome ^ (x.syndrome >> 12)) & 0xFFFF; bloom[h >> 5] |= 1u << (h & 31); }
+    uint32_t *pb = nullptr;
+    HIP_TRY (hipMalloc (reinterpret_cast<void **> (&pb), bloom.size () * sizeof (uint32_t)));
+    HIP_TRY (hipMemcpy (pb, bloom.data (), bloom.size () * sizeof (uint32_t), hipMemcpyHostToDevice));
+    if (bits == kShortBits) { t.short_tab = p; t.short_n = int (d.size ()); t.bloom_short = pb; }
+    else                    { t.long_tab = p;  t.long_n = int (d.size ()); t.bloom_long = pb; }
   }
   HIP_TRY (hipMalloc (reinterpret_cast<void **> (&e->d_stats), 8 * sizeof (unsigned long long)));
   return MODES_OK;
@@ -148,7 +154,8 @@ int fill_scan_params (modes_engine *e, const void *d_iq, size_t nbytes, const ui
   int rc;
   if ((rc = e->records.reserve (size_t (nstrips) * e->cap)) != MODES_OK) return rc;
   if ((rc = e->counts.reserve (nstrips)) != MODES_OK) return rc;
-  if ((rc = e->vp_bitmap.reserve (size_t (nstrips) * 64)) != MODES_OK) return rc;
+  if ((rc = e->vp_counts.reserve (nstrips)) != MODES_OK) return rc;
+  if ((rc = e->vp_bitmap.reserve (size_t (nstrips) * kWords)) != MODES_OK) return rc;
   memset (sp, 0, sizeof *sp);
   sp->iq = static_cast<const uint8_t *> (d_iq);
   sp->nsamples = nsamples;
@@ -160,13 +167,15 @@ int fill_scan_params (modes_engine *e, const void *d_iq, size_t nbytes, const ui
   sp->short_tab = e->tabs.short_tab; sp->short_n = e->tabs.short_n;
   sp->long_tab = e->tabs.long_tab;   sp->long_n = e->tabs.long_n;
   sp->lut256 = e->tabs.lut256;
+  sp->bloom_short = e->tabs.bloom_short; sp->bloom_long = e->tabs.bloom_long;
   sp->records = e->records.p;
   sp->counts = e->counts.p;
   sp->cap = e->cap;
   sp->nstrips = nstrips;
-  sp->stats = e->d_stats;
+  sp->vp_counts = e->vp_counts.p;
   sp->write_records = 1;
   sp->vp_bitmap = e->vp_bitmap.p;
+  sp->debug_stop = 0;
   return MODES_OK;
 }
 
@@ -196,7 +205,7 @@ int modes_engine_create (const modes_engine_config *cfg, modes_engine **out)
   e->conv = conv;
   e->ov = trailing_samples (cfg->sample_rate);
   e->block_samples = kAsyncBufSize / bytes_per_sample (cfg->input_format);
-  e->cap = cfg->phase_enhance ? 256 : 64;
+  e->cap = cfg->phase_enhance ? 128 : 32;
   memset (&e->stats, 0, sizeof e->stats);
   int rc = setup_tables (e);
   if (rc != MODES_OK) { modes_engine_destroy (e); return rc; }
@@ -210,11 +219,13 @@ void modes_engine_destroy (modes_engine *e)
 {
   if (!e) return;
   e->records.release (); e->packed.release (); e->counts.release (); e->rssi_len.release ();
-  e->chunk_sum.release (); e->packed_pos.release (); e->offsets.release (); e->rssi_pos.release ();
+  e->chunk_sum.release (); e->chunk_vp.release (); e->chunk_ovf.release (); e->vp_counts.release (); e->packed_pos.release (); e->offsets.release (); e->rssi_pos.release ();
   e->rssi_sum.release (); e->staging.release (); e->tail.release (); e->vp_bitmap.release ();
   if (e->tabs.short_tab) (void) hipFree (e->tabs.short_tab);
   if (e->tabs.long_tab) (void) hipFree (e->tabs.long_tab);
   if (e->tabs.lut256) (void) hipFree (e->tabs.lut256);
+  if (e->tabs.bloom_short) (void) hipFree (e->tabs.bloom_short);
+  if (e->tabs.bloom_long) (void) hipFree (e->tabs.bloom_long);
   if (e->d_stats) (void) hipFree (e->d_stats);
   delete e;
 }
@@ -248,28 +259,32 @@ int modes_engine_run_device (modes_engine *e, const void *d_iq, size_t nbytes, u
   if (rc != MODES_OK) return rc;
   if (sp.nstrips == 0) return MODES_OK;
 
-  HIP_TRY (hipMemsetAsync (e->d_stats, 0, 8 * sizeof (unsigned long long), stream));
   HIP_TRY (launch_scan2400 (sp, stream));
 
-  // compact the per-strip slots into one ordered list
+  // totals, then compact the per-strip slots into one ordered list
   const uint32_t nchunks = (sp.nstrips + 1023) / 1024;
-  if ((rc = e->chunk_sum.reserve (nchunks + 2)) != MODES_OK) return rc;
+  if ((rc = e->chunk_sum.reserve (nchunks + 1)) != MODES_OK) return rc;
+  if ((rc = e->chunk_vp.reserve (nchunks + 1)) != MODES_OK) return rc;
+  if ((rc = e->chunk_ovf.reserve (nchunks + 1)) != MODES_OK) return rc;
   if ((rc = e->offsets.reserve (sp.nstrips)) != MODES_OK) return rc;
-  unsigned long long st[8];
-  HIP_TRY (hipMemcpyAsync (st, e->d_stats, sizeof st, hipMemcpyDeviceToHost, stream));
+  uint64_t *d_totals = reinterpret_cast<uint64_t *> (e->d_stats);
+  HIP_TRY (launch_count_scan (e->counts.p, e->vp_counts.p, sp.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p,
+                              d_totals, stream));
+  unsigned long long st[3];
+  HIP_TRY (hipMemcpyAsync (st, d_totals, sizeof st, hipMemcpyDeviceToHost, stream));
   HIP_TRY (hipStreamSynchronize (stream));
   if (st[2]) return fail (MODES_E_OVERFLOW, "%llu strips overflowed their candidate slots (cap %u)", st[2], e->cap);
-  const size_t nrec = size_t (st[1]);
-  e->stats.valid_preamble = st[0];
+  const size_t nrec = size_t (st[0]);
+  e->stats.valid_preamble = st[1];
   e->stats.candidates = nrec;
   if ((rc = e->packed.reserve (nrec + 1)) != MODES_OK) return rc;
   if ((rc = e->packed_pos.reserve (nrec + 1)) != MODES_OK) return rc;
-  HIP_TRY (launch_compact (e->counts.p, sp.nstrips, e->chunk_sum.p, e->records.p, e->cap, e->packed.p, e->packed_pos.p,
-                           e->offsets.p, stream));
+  HIP_TRY (launch_gather (e->counts.p, sp.nstrips, e->chunk_sum.p, e->records.p, e->cap, e->packed.p, e->packed_pos.p,
+                          e->offsets.p, stream));
 
   std::vector<Record> recs (nrec);
   std::vector<uint64_t> pos (nrec);
-  std::vector<uint64_t> vp (size_t (sp.nstrips) * 64);
+  std::vector<uint64_t> vp (size_t (sp.nstrips) * kWords);
   HIP_TRY (hipMemcpyAsync (vp.data (), e->vp_bitmap.p, vp.size () * sizeof (uint64_t), hipMemcpyDeviceToHost, stream));
   if (nrec) {
     HIP_TRY (hipMemcpyAsync (recs.data (), e->packed.p, nrec * sizeof (Record), hipMemcpyDeviceToHost, stream));
@@ -330,10 +345,10 @@ int modes_engine_time_scan (modes_engine *e, const void *d_iq, size_t nbytes, in
   ScanParams sp;
   int rc = fill_scan_params (e, d_iq, nbytes, nullptr, &sp);
   if (rc != MODES_OK) return rc;
+  if (const char *ds = getenv ("MODES_DEBUG_STOP")) sp.debug_stop = atoi (ds);
   hipEvent_t a, b;
   HIP_TRY (hipEventCreate (&a));
   HIP_TRY (hipEventCreate (&b));
-  HIP_TRY (hipMemsetAsync (e->d_stats, 0, 8 * sizeof (unsigned long long), stream));
   HIP_TRY (hipEventRecord (a, stream));
   for (int i = 0; i < reps; i++) HIP_TRY (launch_scan2400 (sp, stream));
   HIP_TRY (hipEventRecord (b, stream));

@@ -46,14 +46,34 @@ __device__ __forceinline__ uint16_t mag_from_float (float fI, float fQ, float *m
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lane_id () { return int (__builtin_amdgcn_mbcnt_hi (~0u, __builtin_amdgcn_mbcnt_lo (~0u, 0u))); }
 
+
+// ---- DPP cross-lane helpers (GFX9 row/wave controls; no LDS round trip) ----
+template <int CTRL, int ROW_MASK = 0xF, bool BOUND = true>
+__device__ __forceinline__ uint32_t dpp_mov (uint32_t v)
+{
+  return uint32_t (__builtin_amdgcn_update_dpp (0, int (v), CTRL, ROW_MASK, 0xF, BOUND));
+}
+// every lane of a 16-lane row receives the XOR / OR of the row (row_ror:1,2,4,8)
+__device__ __forceinline__ uint32_t row_xor (uint32_t v)
+{
+  v ^= dpp_mov<0x121> (v); v ^= dpp_mov<0x122> (v); v ^= dpp_mov<0x124> (v); v ^= dpp_mov<0x128> (v);
+  return v;
+}
+__device__ __forceinline__ uint32_t row_or (uint32_t v)
+{
+  v |= dpp_mov<0x121> (v); v |= dpp_mov<0x122> (v); v |= dpp_mov<0x124> (v); v |= dpp_mov<0x128> (v);
+  return v;
+}
+
+// inclusive +scan over the 64 lanes: row_shr 1,2,4,8 inside each row, then row_bcast:15 / row_bcast:31
 __device__ __forceinline__ int wave_incl_scan (int v, int lane)
 {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    int o = __shfl_up (v, d, 64);
-    if (lane >= d) v += o;
-  }
-  return v;
+  (void) lane;
+  uint32_t u = uint32_t (v);
+  u += dpp_mov<0x111> (u); u += dpp_mov<0x112> (u); u += dpp_mov<0x114> (u); u += dpp_mov<0x118> (u);
+  u += dpp_mov<0x142, 0xA, false> (u);
+  u += dpp_mov<0x143, 0xC, false> (u);
+  return int (u);
 }
 
 __device__ __forceinline__ uint32_t wave_xor (uint32_t v)
@@ -128,11 +148,11 @@ __device__ __forceinline__ int table_find (const ErrEntry *tab, int n, uint32_t 
 // LDS per wave
 struct WaveLds {
   uint16_t tile[kStrip + kLook2400 + kTilePad];   // magnitudes V[P0 - shift ...]
-  uint16_t q1[2048];                              // off | pattern << 12
-  uint32_t q2[1024];                              // off | (t-4) << 12 | df << 16
+  uint16_t q1[kQ1Cap];                            // off | pattern << 12
+  uint32_t q2[kQ2Cap];                              // off | (t-4) << 12 | df << 16
   uint16_t lut[256];                              // as-written uc8 table
   uint32_t sb[kLongBits];
-  u64      vp[64];                                // valid-preamble bit per position of the strip
+  u64      vp[kWords];                                // valid-preamble bit per position of the strip
 };
 
 constexpr int kWavesPerBlock = 4;
@@ -140,44 +160,87 @@ constexpr int kWavesPerBlock = 4;
 // ------------------------------------------------------------------------------------------
 // staging: convert samples [a_lo, a_lo + count) into w.tile[0 .. count)
 // ------------------------------------------------------------------------------------------
+template <int CONV> struct RawWords { static constexpr int n = (CONV == kConvUc8Lut || CONV == kConvUc8LutPower) ? 2 : (CONV == kConvUc8Generic) ? 4 : 8; };
+
+// raw IQ of 8 consecutive samples starting at n0 (a multiple of 8, whole chunk inside the shard)
 template <int CONV>
-__device__ __forceinline__ void stage_tile (WaveLds &w, const ScanParams &p, long long a_lo, int count, int lane)
+__device__ __forceinline__ void load_raw8 (const ScanParams &p, long long n0, uint32_t *d)
+{
+  if (CONV == kConvUc8Lut || CONV == kConvUc8LutPower) {
+    // as written: output sample i of a block reads input BYTE i of that block (ref: src/convert.c:19,29)
+    const uint64_t blk = uint64_t (n0) / p.block_samples, i = uint64_t (n0) % p.block_samples;
+    const uint2 v = *reinterpret_cast<const uint2 *> (p.iq + blk * 2 * p.block_samples + i);
+    d[0] = v.x; d[1] = v.y;
+  } else if (CONV == kConvUc8Generic) {
+    const uint4 v = *reinterpret_cast<const uint4 *> (p.iq + 2 * n0);
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  } else {
+    const uint4 *src = reinterpret_cast<const uint4 *> (p.iq + 4 * n0);
+    const uint4 v0 = src[0], v1 = src[1];
+    d[0] = v0.x; d[1] = v0.y; d[2] = v0.z; d[3] = v0.w; d[4] = v1.x; d[5] = v1.y; d[6] = v1.z; d[7] = v1.w;
+  }
+}
+
+template <int CONV>
+__device__ __forceinline__ uint4 convert_raw8 (const WaveLds &w, const uint32_t *d)
+{
+  uint16_t out[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (CONV == kConvUc8Lut || CONV == kConvUc8LutPower)
+      out[k] = w.lut[(d[k >> 2] >> (8 * (k & 3))) & 0xFF];
+    else if (CONV == kConvUc8Generic) {
+      const uint32_t iqp = d[k >> 1] >> (16 * (k & 1));
+      out[k] = mag_from_float (c_uc8_float[iqp & 0xFF], c_uc8_float[(iqp >> 8) & 0xFF], nullptr);
+    } else {
+      const int I = int (int16_t (d[k] & 0xFFFF)), Q = int (int16_t (d[k] >> 16));
+      if (CONV == kConvSc16Int) out[k] = mag_sc16_int (I, Q);
+      else {
+        const float sc = CONV == kConvSc16Generic ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
+        out[k] = mag_from_float (float (I) * sc, float (Q) * sc, nullptr);
+      }
+    }
+  }
+  uint4 pk;
+  pk.x = out[0] | (uint32_t (out[1]) << 16); pk.y = out[2] | (uint32_t (out[3]) << 16);
+  pk.z = out[4] | (uint32_t (out[5]) << 16); pk.w = out[6] | (uint32_t (out[7]) << 16);
+  return pk;
+}
+
+constexpr int kTileCount = kStrip + kLook2400 + kTilePad;
+constexpr int kTileChunks = kTileCount / 8;
+constexpr int kTileIters = (kTileChunks + 63) / 64;
+
+template <int CONV>
+__device__ __forceinline__ void stage_tile (WaveLds &w, const ScanParams &p, long long a_lo, int lane)
 {
   const long long N = (long long) p.nsamples;
-  for (int c = lane * 8; c < count; c += 64 * 8) {
+  constexpr int NW = RawWords<CONV>::n;
+  if (a_lo >= 0 && a_lo + kTileCount <= N) {
+    // interior strip: every load is issued before the first conversion
+    uint32_t raw[kTileIters][NW];
+#pragma unroll
+    for (int it = 0; it < kTileIters; it++) {
+      const int ch = it * 64 + lane;
+      if (ch < kTileChunks) load_raw8<CONV> (p, a_lo + 8 * ch, raw[it]);
+    }
+#pragma unroll
+    for (int it = 0; it < kTileIters; it++) {
+      const int ch = it * 64 + lane;
+      if (ch < kTileChunks) *reinterpret_cast<uint4 *> (&w.tile[8 * ch]) = convert_raw8<CONV> (w, raw[it]);
+    }
+    return;
+  }
+  // first / last strips of the shard: per-sample bounds
+  for (int c = lane * 8; c < kTileCount; c += 64 * 8) {
     const long long n0 = a_lo + c;
-    uint16_t out[8];
+    uint4 pk;
     if (n0 >= 0 && n0 + 8 <= N) {
-      if (CONV == kConvUc8Lut || CONV == kConvUc8LutPower) {
-        // as written: output sample i of a block reads input BYTE i of that block (ref: src/convert.c:19,29)
-        const uint64_t blk = uint64_t (n0) / p.block_samples, i = uint64_t (n0) % p.block_samples;
-        const uint2 v = *reinterpret_cast<const uint2 *> (p.iq + blk * 2 * p.block_samples + i);
-        const uint32_t d[2] = { v.x, v.y };
-#pragma unroll
-        for (int k = 0; k < 8; k++) out[k] = w.lut[(d[k >> 2] >> (8 * (k & 3))) & 0xFF];
-      } else if (CONV == kConvUc8Generic) {
-        const uint4 v = *reinterpret_cast<const uint4 *> (p.iq + 2 * n0);
-        const uint32_t d[4] = { v.x, v.y, v.z, v.w };
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-          const uint32_t iqp = d[k >> 1] >> (16 * (k & 1));
-          out[k] = mag_from_float (c_uc8_float[iqp & 0xFF], c_uc8_float[(iqp >> 8) & 0xFF], nullptr);
-        }
-      } else {
-        const uint4 *src = reinterpret_cast<const uint4 *> (p.iq + 4 * n0);
-        const uint4 v0 = src[0], v1 = src[1];
-        const uint32_t d[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-          const int I = int (int16_t (d[k] & 0xFFFF)), Q = int (int16_t (d[k] >> 16));
-          if (CONV == kConvSc16Int) out[k] = mag_sc16_int (I, Q);
-          else {
-            const float sc = CONV == kConvSc16Generic ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
-            out[k] = mag_from_float (float (I) * sc, float (Q) * sc, nullptr);
-          }
-        }
-      }
+      uint32_t d[NW];
+      load_raw8<CONV> (p, n0, d);
+      pk = convert_raw8<CONV> (w, d);
     } else {
+      uint16_t out[8];
 #pragma unroll
       for (int k = 0; k < 8; k++) {
         const long long n = n0 + k;
@@ -201,10 +264,9 @@ __device__ __forceinline__ void stage_tile (WaveLds &w, const ScanParams &p, lon
         }
         out[k] = m;
       }
+      pk.x = out[0] | (uint32_t (out[1]) << 16); pk.y = out[2] | (uint32_t (out[3]) << 16);
+      pk.z = out[4] | (uint32_t (out[5]) << 16); pk.w = out[6] | (uint32_t (out[7]) << 16);
     }
-    uint4 pk;
-    pk.x = out[0] | (uint32_t (out[1]) << 16); pk.y = out[2] | (uint32_t (out[3]) << 16);
-    pk.z = out[4] | (uint32_t (out[5]) << 16); pk.w = out[6] | (uint32_t (out[7]) << 16);
     *reinterpret_cast<uint4 *> (&w.tile[c]) = pk;
   }
 }
@@ -226,35 +288,37 @@ void scan2400_kernel (const ScanParams p)
   // wave-private tables
   for (int i = lane; i < 256; i += 64) w.lut[i] = p.lut256 ? p.lut256[i] : uint16_t (0);
   for (int i = lane; i < kLongBits; i += 64) w.sb[i] = c_single_bit[i];
-  w.vp[lane] = 0;
+  if (lane < kWords) w.vp[lane] = 0;
 
   // ---- stage A: magnitudes of V[P0 .. P0 + kStrip + kLook2400) into LDS ----
   const long long P0 = (long long) strip * kStrip;
   const long long s0 = P0 - (long long) p.ov;                 // first sample index needed (may be < 0)
   const long long a_lo = (s0 >= 0 ? s0 : s0 - 15) / 16 * 16;  // floor to a multiple of 16
   const int shift = int (s0 - a_lo);                          // V[P0 + x] == tile[x + shift]
-  stage_tile<CONV> (w, p, a_lo, kStrip + kLook2400 + kTilePad, lane);
+  stage_tile<CONV> (w, p, a_lo, lane);
   __builtin_amdgcn_s_waitcnt (0xc07f);   // lgkmcnt(0): LDS writes of this wave are done (wave-private data)
   __builtin_amdgcn_wave_barrier ();
 
   const uint16_t *V = w.tile + shift;
+  if (p.debug_stop == 1) { if (lane == 0) p.counts[strip] = V[lane]; return; }
 
   // ---- stage B: LT/GT bit planes; lane l ends up owning word l = positions [64 l, 64 l + 64) ----
   uint32_t lt_lo = 0, lt_hi = 0, gt_lo = 0, gt_hi = 0;
   u64 lt_last = 0, gt_last = 0;
-#pragma unroll 5
-  for (int s = 0; s <= 64; s++) {
+#pragma unroll 3
+  for (int s = 0; s <= kWords; s++) {
     const int x = 64 * s + lane;
     const uint32_t a = V[x], b = V[x + 1];
     const u64 lt = __ballot (a < b), gt = __ballot (a > b);
-    if (s < 64) {
+    if (s < kWords) {
       if (lane == s) { lt_lo = uint32_t (lt); lt_hi = uint32_t (lt >> 32); gt_lo = uint32_t (gt); gt_hi = uint32_t (gt >> 32); }
     } else { lt_last = lt; gt_last = gt; }
   }
   const u64 LT = (u64 (lt_hi) << 32) | lt_lo, GT = (u64 (gt_hi) << 32) | gt_lo;
   u64 LTn = (u64 (uint32_t (__shfl_down (int (lt_hi), 1, 64))) << 32) | uint32_t (__shfl_down (int (lt_lo), 1, 64));
   u64 GTn = (u64 (uint32_t (__shfl_down (int (gt_hi), 1, 64))) << 32) | uint32_t (__shfl_down (int (gt_lo), 1, 64));
-  if (lane == 63) { LTn = lt_last; GTn = gt_last; }
+  if (lane == kWords - 1) { LTn = lt_last; GTn = gt_last; }
+  if (lane >= kWords) { LTn = 0; GTn = 0; }
 
   // peaks P_k = (p[k] < p[k+1] > p[k+2]); the five layouts of ref: src/demod-2400.c:225-282 with the
   // quick check (p0 < p1, p12 > p13) folded in.
@@ -278,11 +342,12 @@ void scan2400_kernel (const ScanParams p)
     else if (base + 64 > N) any &= (~0ull) >> (64 - int (N - base));
   }
 
+  if (p.debug_stop == 2) { if (any == 0x1234567ull) p.counts[strip] = 1; return; }
   // ---- queue 1: candidate positions in ascending order ----
   const int mycnt = __popcll (any);
   const int incl = wave_incl_scan (mycnt, lane);
   const int n1 = __shfl (incl, 63, 64);
-  bool overflow = n1 > 2048;
+  bool overflow = n1 > kQ1Cap;
   if (!overflow) {
     int slot = incl - mycnt;
     u64 mm = any;
@@ -348,7 +413,7 @@ void scan2400_kernel (const ScanParams p)
     if (pass) atomicOr (&w.vp[off >> 6], 1ull << (off & 63));
     const int inc = wave_incl_scan (nent, lane);
     const int tot = __shfl (inc, 63, 64);
-    if (n2 + tot > 1024) { overflow = true; break; }
+    if (n2 + tot > kQ2Cap) { overflow = true; break; }
     int slot = n2 + inc - nent;
     for (int k = 0; k < nent; k++) w.q2[slot + k] = ent[k];
     n2 += tot;
@@ -356,79 +421,108 @@ void scan2400_kernel (const ScanParams p)
   __builtin_amdgcn_s_waitcnt (0xc07f);
   __builtin_amdgcn_wave_barrier ();
 
-  // ---- stage D: 56/112-bit slicing + CRC, the whole wave on one candidate ----
+  if (p.debug_stop == 3) { if (lane == 0) p.counts[strip] = n2 + valid_preamble; return; }
+  // ---- stage D: 56/112-bit slicing + CRC; 16 lanes per candidate, lane r of a row slices byte r ----
   uint32_t nrec = 0;
   Record *out = p.records + size_t (strip) * p.cap;
-  for (int qi = 0; qi < n2 && !overflow; qi++) {
-    const uint32_t e = __builtin_amdgcn_readfirstlane (w.q2[qi]);   // same entry for the whole wave
+  const int row = lane >> 4, r = lane & 15;
+  for (int base = 0; base < n2 && !overflow; base += 4) {
+    const int ci = base + row;
+    const bool act = ci < n2;
+    const uint32_t e = act ? w.q2[ci] : 0u;
     const int off = e & 0xFFF, t = 4 + int ((e >> 12) & 7), df = int (e >> 16);
-    const int nslice = slice_bytes_for_df (df) * 8;       // 56 or 112
-    const int ncrc = msg_bits_for_df (df);                // bits the score's CRC runs over
+    const int nbytes = act ? slice_bytes_for_df (df) : 0;   // 7 or 14 (ref: src/demod-2400.c:416-435)
+    const int ncrc = msg_bits_for_df (df);                  // bits the score's CRC runs over
     const uint16_t *m = V + off + 19;
-    u64 bits[2];
+    uint32_t byte = 0;
+    if (r < nbytes) {
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int k = 64 * h + lane;
-      bool one = false;
-      if (k < nslice) {
-        const int f = t + 12 * k;
-        const int i = (f * 0xCCCD) >> 18, r = f - 5 * i;
+      for (int k = 0; k < 8; k++) {
+        const int f = t + 12 * (8 * r + k);
+        const int i = (f * 0xCCCD) >> 18, ph = f - 5 * i;
         const int a0 = m[i], a1 = m[i + 1], a2 = m[i + 2], a3 = m[i + 3];
-        const int w2 = r < 3 ? 2 + r : 5;
-        const int v = (5 - r) * a0 + (2 * r - 3) * a1 - w2 * a2 - (r == 4 ? a3 : 0);
-        one = v > 0;
+        const int w2 = ph < 3 ? 2 + ph : 5;
+        const int v = (5 - ph) * a0 + (2 * ph - 3) * a1 - w2 * a2 - (ph == 4 ? a3 : 0);
+        byte = (byte << 1) | uint32_t (v > 0);
       }
-      bits[h] = __ballot (one);
     }
-    // syndrome = XOR of the single-bit syndromes of the set bits (the CRC is linear)
-    const int sbo = kLongBits - ncrc;
+    // syndrome = XOR of the single-bit syndromes of the set bits (the CRC is linear, ref: src/crc.c:56-61)
+    const bool in_crc = 8 * r < ncrc;
     uint32_t x = 0;
-    if (lane < ncrc && ((bits[0] >> lane) & 1)) x ^= w.sb[lane + sbo];
-    if (64 + lane < ncrc && ((bits[1] >> lane) & 1)) x ^= w.sb[64 + lane + sbo];
-    const uint32_t syn = wave_xor (x);
-    const u64 live0 = ncrc >= 64 ? bits[0] : (bits[0] & ((1ull << ncrc) - 1));
-    const u64 live1 = ncrc > 64 ? (bits[1] & ((1ull << (ncrc - 64)) - 1)) : 0;
-    if ((live0 | live1) == 0) continue;                    // all-zero message (ref: src/dump1090.c:3295)
+    if (in_crc && byte) {
+      const uint32_t *sb = &w.sb[8 * r + (kLongBits - ncrc)];
+#pragma unroll
+      for (int k = 0; k < 8; k++) if ((byte >> (7 - k)) & 1) x ^= sb[k];
+    }
+    const uint32_t syn = row_xor (x);
+    const uint32_t live = row_or (in_crc ? byte : 0u);       // all-zero message -> -2 (ref: src/dump1090.c:3295)
+    const uint32_t part = byte << (8 * (r & 3));
+    const uint32_t w0 = row_or ((r >> 2) == 0 ? part : 0u), w1 = row_or ((r >> 2) == 1 ? part : 0u);
+    const uint32_t w2 = row_or ((r >> 2) == 2 ? part : 0u), w3 = row_or ((r >> 2) == 3 ? part : 0u);
 
+    bool keep = act && live != 0;
     int cls, nerr = 0, b0 = 0, b1 = 0;
-    if (df == 17 || df == 18 || df == 11) {
-      const uint32_t key = df == 11 ? (syn & 0xFFFF80u) : syn;
-      cls = df == 11 ? kClsDF11 : kClsES;
-      if (key != 0) {
-        const ErrEntry *tab = ncrc == kShortBits ? p.short_tab : p.long_tab;
-        const int tn = ncrc == kShortBits ? p.short_n : p.long_n;
-        const int hit = table_find (tab, tn, key, lane);
-        if (hit < 0) continue;                             // uncorrectable (ref: src/dump1090.c:3315,3343)
-        const ErrEntry te = tab[hit];
-        nerr = te.nerr; b0 = te.bit0; b1 = te.bit1;
-        if (df == 11 && nerr > 1) continue;                // ref: src/dump1090.c:3322
+    const bool es = df == 17 || df == 18, acq = df == 11;
+    if (es || acq) {
+      cls = acq ? kClsDF11 : kClsES;
+      const uint32_t key = acq ? (syn & 0xFFFF80u) : syn;
+      const bool shortt = ncrc == kShortBits;
+      const ErrEntry *tab = shortt ? p.short_tab : p.long_tab;
+      const int tn = shortt ? p.short_n : p.long_n;
+      bool need = keep && key != 0;
+      if (need) {                                           // 64 Kbit filter in front of the table
+        const uint32_t h = (key ^ (key >> 12)) & 0xFFFF;
+        const uint32_t *bloom = shortt ? p.bloom_short : p.bloom_long;
+        need = tn > 0 && ((bloom[h >> 5] >> (h & 31)) & 1);
+        if (!need) keep = false;                            // uncorrectable (ref: src/dump1090.c:3315,3343)
+      }
+      if (__ballot (need)) {
+        int lo = 0, len = need ? tn : 0;
+#pragma unroll
+        for (int level = 0; level < 3; level++) {           // 16-ary search, tables hold <= 4096 entries
+          const int step = len > 16 ? (len + 15) >> 4 : 1;
+          const int idx = lo + r * step;
+          const bool le = r * step < len && tab[idx].syndrome <= key;
+          const uint32_t rowbits = uint32_t (__ballot (le) >> (16 * row)) & 0xFFFFu;
+          if (rowbits == 0) len = 0;
+          else {
+            const int seg = 31 - __builtin_clz (rowbits);
+            lo += seg * step;
+            len = min (step, len - seg * step);
+          }
+        }
+        if (need) {
+          ErrEntry te = { 0, 0, 0, 0, 0 };
+          if (len > 0) te = tab[lo];
+          if (len > 0 && te.syndrome == key && !(acq && te.nerr > 1)) { nerr = te.nerr; b0 = te.bit0; b1 = te.bit1; }
+          else keep = false;                                // ref: src/dump1090.c:3315,3322,3343
+        }
       }
     } else
       cls = (df == 20 || df == 21) ? kClsAP2 : kClsAP;
 
-    if (nrec >= p.cap) { overflow = true; break; }
-    if (lane == 0 && p.write_records) {
-      const uint32_t w0 = rev_in_bytes (uint32_t (bits[0])), w1 = rev_in_bytes (uint32_t (bits[0] >> 32));
-      const uint32_t w2 = rev_in_bytes (uint32_t (bits[1])), w3 = rev_in_bytes (uint32_t (bits[1] >> 32));
+    const u64 kept = __ballot (keep && r == 0);
+    const uint32_t slot = nrec + uint32_t (__popcll (kept & ((1ull << lane) - 1)));
+    const uint32_t total = nrec + uint32_t (__popcll (kept));
+    if (total > p.cap) { overflow = true; break; }
+    if (keep && r == 0 && p.write_records) {
       // Record layout: off,phase,df | cls,nerr,bit0,bit1 | crc | msg[0..13] | flags,pad
-      uint4 lo, hi;
-      lo.x = uint32_t (off) | (uint32_t (t) << 16) | (uint32_t (df) << 24);
-      lo.y = uint32_t (cls) | (uint32_t (uint8_t (nerr)) << 8) | (uint32_t (uint8_t (b0)) << 16) | (uint32_t (uint8_t (b1)) << 24);
-      lo.z = syn;
-      lo.w = w0;
-      hi.x = w1; hi.y = w2; hi.z = w3 & 0xFFFF; hi.w = 0;
-      uint4 *dst = reinterpret_cast<uint4 *> (out + nrec);
-      dst[0] = lo; dst[1] = hi;
+      uint4 lo4, hi4;
+      lo4.x = uint32_t (off) | (uint32_t (t) << 16) | (uint32_t (df) << 24);
+      lo4.y = uint32_t (cls) | (uint32_t (uint8_t (nerr)) << 8) | (uint32_t (uint8_t (b0)) << 16) | (uint32_t (uint8_t (b1)) << 24);
+      lo4.z = syn;
+      lo4.w = w0;
+      hi4.x = w1; hi4.y = w2; hi4.z = w3 & 0xFFFF; hi4.w = 0;
+      uint4 *dst = reinterpret_cast<uint4 *> (out + slot);
+      dst[0] = lo4; dst[1] = hi4;
     }
-    nrec++;
+    nrec = total;
   }
 
-  if (p.vp_bitmap) p.vp_bitmap[size_t (strip) * 64 + lane] = w.vp[lane];
-  if (lane == 0) {
+  if (p.vp_bitmap && lane < kWords) p.vp_bitmap[size_t (strip) * kWords + lane] = w.vp[lane];
+  if (lane == 0) {      // per-strip results only: no contended atomics
     p.counts[strip] = overflow ? 0xFFFFFFFFu : nrec;
-    if (valid_preamble) atomicAdd (&p.stats[0], (u64) valid_preamble);
-    if (nrec) atomicAdd (&p.stats[1], (u64) nrec);
-    if (overflow) atomicAdd (&p.stats[2], 1ull);
+    p.vp_counts[strip] = valid_preamble;
   }
 }
 
@@ -519,29 +613,38 @@ constexpr int kScanChunk = 1024;
 __device__ __forceinline__ uint32_t clean_count (uint32_t c) { return c == 0xFFFFFFFFu ? 0u : c; }
 
 __global__ __launch_bounds__ (256)
-void chunk_sums_kernel (const uint32_t *counts, uint32_t n, uint64_t *chunk_sum)
+void chunk_sums_kernel (const uint32_t *counts, const uint32_t *vp_counts, uint32_t n, uint64_t *chunk_sum,
+                        uint64_t *chunk_vp, uint64_t *chunk_ovf)
 {
-  __shared__ uint32_t part[4];
+  __shared__ uint32_t part[3][4];
   const uint32_t base = blockIdx.x * kScanChunk;
-  uint32_t s = 0;
-  for (uint32_t i = threadIdx.x; i < kScanChunk; i += 256) if (base + i < n) s += clean_count (counts[base + i]);
-  for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor (int (s), d, 64);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  uint32_t s = 0, v = 0, o = 0;
+  for (uint32_t i = threadIdx.x; i < kScanChunk; i += 256)
+    if (base + i < n) { const uint32_t c = counts[base + i]; s += clean_count (c); o += c == 0xFFFFFFFFu; v += vp_counts[base + i]; }
+  for (int d = 32; d >= 1; d >>= 1) { s += __shfl_xor (int (s), d, 64); v += __shfl_xor (int (v), d, 64); o += __shfl_xor (int (o), d, 64); }
+  if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = s; part[1][threadIdx.x >> 6] = v; part[2][threadIdx.x >> 6] = o; }
   __syncthreads ();
-  if (threadIdx.x == 0) chunk_sum[blockIdx.x] = u64 (part[0]) + part[1] + part[2] + part[3];
+  if (threadIdx.x == 0) {
+    chunk_sum[blockIdx.x] = u64 (part[0][0]) + part[0][1] + part[0][2] + part[0][3];
+    chunk_vp[blockIdx.x]  = u64 (part[1][0]) + part[1][1] + part[1][2] + part[1][3];
+    chunk_ovf[blockIdx.x] = u64 (part[2][0]) + part[2][1] + part[2][2] + part[2][3];
+  }
 }
 
-// single workgroup: exclusive scan of chunk sums in place; total goes to chunk_sum[nchunks]
+// single workgroup: exclusive scan of chunk sums in place; totals go to totals[0..2] = records, valid preambles, overflowed strips
 __global__ __launch_bounds__ (1024)
-void scan_chunk_sums_kernel (uint64_t *chunk_sum, uint32_t nchunks)
+void scan_chunk_sums_kernel (uint64_t *chunk_sum, const uint64_t *chunk_vp, const uint64_t *chunk_ovf, uint32_t nchunks,
+                             uint64_t *totals)
 {
   __shared__ uint64_t buf[1024];
   __shared__ uint64_t carry;
   if (threadIdx.x == 0) carry = 0;
   __syncthreads ();
+  uint64_t vp = 0, ovf = 0;
   for (uint32_t base = 0; base < nchunks; base += 1024) {
     const uint32_t i = base + threadIdx.x;
     const uint64_t v = i < nchunks ? chunk_sum[i] : 0;
+    if (i < nchunks) { vp += chunk_vp[i]; ovf += chunk_ovf[i]; }
     buf[threadIdx.x] = v;
     __syncthreads ();
     for (int d = 1; d < 1024; d <<= 1) {
@@ -555,7 +658,16 @@ void scan_chunk_sums_kernel (uint64_t *chunk_sum, uint32_t nchunks)
     if (threadIdx.x == 1023) carry += buf[1023];
     __syncthreads ();
   }
-  if (threadIdx.x == 0) chunk_sum[nchunks] = carry;
+  // reduce vp / ovf over the workgroup
+  buf[threadIdx.x] = vp;
+  __syncthreads ();
+  for (int d = 512; d >= 1; d >>= 1) { if (threadIdx.x < (unsigned) d) buf[threadIdx.x] += buf[threadIdx.x + d]; __syncthreads (); }
+  const uint64_t vp_total = buf[0];
+  __syncthreads ();
+  buf[threadIdx.x] = ovf;
+  __syncthreads ();
+  for (int d = 512; d >= 1; d >>= 1) { if (threadIdx.x < (unsigned) d) buf[threadIdx.x] += buf[threadIdx.x + d]; __syncthreads (); }
+  if (threadIdx.x == 0) { totals[0] = carry; totals[1] = vp_total; totals[2] = buf[0]; }
 }
 
 // one wave per strip: offsets[strip] = chunk base + scan inside the chunk; copies the strip's records
@@ -643,18 +755,25 @@ hipError_t launch_rssi2400 (int conv, const uint8_t *iq, uint64_t nsamples, cons
   return hipGetLastError ();
 }
 
-// counts[nstrips] -> offsets[nstrips], packed records/positions; chunk_sum needs nstrips/1024 + 2 entries.
-// The grand total is left in chunk_sum[nchunks].
-hipError_t launch_compact (const uint32_t *counts, uint32_t nstrips, uint64_t *chunk_sum, const Record *records,
-                           uint32_t cap, Record *packed, uint64_t *packed_pos, uint64_t *offsets, hipStream_t stream)
+// Step 1: per-chunk sums + exclusive scan; totals[0..2] = records, valid preambles, overflowed strips.
+// chunk_sum / chunk_vp / chunk_ovf need nstrips/1024 + 1 entries each.
+hipError_t launch_count_scan (const uint32_t *counts, const uint32_t *vp_counts, uint32_t nstrips, uint64_t *chunk_sum,
+                              uint64_t *chunk_vp, uint64_t *chunk_ovf, uint64_t *totals, hipStream_t stream)
 {
   if (nstrips == 0) return hipSuccess;
   const uint32_t nchunks = (nstrips + kScanChunk - 1) / kScanChunk;
-  hipLaunchKernelGGL (chunk_sums_kernel, dim3 (nchunks), dim3 (256), 0, stream, counts, nstrips, chunk_sum);
-  hipLaunchKernelGGL (scan_chunk_sums_kernel, dim3 (1), dim3 (1024), 0, stream, chunk_sum, nchunks);
-  if (packed)
-    hipLaunchKernelGGL (gather_kernel, dim3 ((nstrips + 3) / 4), dim3 (256), 0, stream, counts, nstrips, chunk_sum, records,
-                        cap, packed, packed_pos, offsets);
+  hipLaunchKernelGGL (chunk_sums_kernel, dim3 (nchunks), dim3 (256), 0, stream, counts, vp_counts, nstrips, chunk_sum, chunk_vp, chunk_ovf);
+  hipLaunchKernelGGL (scan_chunk_sums_kernel, dim3 (1), dim3 (1024), 0, stream, chunk_sum, chunk_vp, chunk_ovf, nchunks, totals);
+  return hipGetLastError ();
+}
+
+// Step 2: gather the per-strip slots into one ordered list.
+hipError_t launch_gather (const uint32_t *counts, uint32_t nstrips, const uint64_t *chunk_sum, const Record *records,
+                          uint32_t cap, Record *packed, uint64_t *packed_pos, uint64_t *offsets, hipStream_t stream)
+{
+  if (nstrips == 0) return hipSuccess;
+  hipLaunchKernelGGL (gather_kernel, dim3 ((nstrips + 3) / 4), dim3 (256), 0, stream, counts, nstrips, chunk_sum, records,
+                      cap, packed, packed_pos, offsets);
   return hipGetLastError ();
 }
 

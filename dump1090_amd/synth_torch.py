@@ -1,0 +1,85 @@
+"""Large synthetic captures generated on the GPU with torch (bench.py): same signal model as
+synth.py (box-integrated OOK pulses, random sub-sample phase / carrier phase / amplitude, AWGN),
+frames drawn from a bank of pre-rendered envelopes so that multi-GiB recordings take seconds."""
+import numpy as np
+import torch
+
+from . import synth
+
+
+def _bank(rng, sample_rate, n_bank, n_icao, df17_fraction):
+    icaos = rng.integers(0x400000, 0x4FFFFF, size=n_icao)
+    envs, msgs = [], []
+    for _ in range(n_bank):
+        icao = int(icaos[rng.integers(0, n_icao)])
+        if rng.random() < df17_fraction:
+            msg = synth.make_df17(icao, bytes(rng.integers(0, 256, size=7, dtype=np.uint8)))
+        else:
+            msg = synth.make_df11(icao)
+        envs.append(synth.envelope(msg, sample_rate, rng.random()))
+        msgs.append(msg)
+    L = max(len(e) for e in envs)
+    bank = np.zeros((n_bank, L), dtype=np.float32)
+    for i, e in enumerate(envs):
+        bank[i, :len(e)] = e
+    return bank, msgs
+
+
+def capture_gpu(nsamples, sample_rate=2.4e6, fmt="uc8", seed=1, frames_per_sec=1000.0, device="cuda:0",
+                noise_sigma=0.01, n_icao=64, n_bank=4096, overlap_fraction=0.1, df17_fraction=0.6,
+                min_amp_db=-32.0, max_amp_db=-4.0, dc_offset=(0.0, 0.0), chunk=1 << 24):
+    """Returns (iq tensor on `device`: uint8[2n] or int16[2n], dict with frame positions / bank indices)."""
+    rng = np.random.default_rng(seed)
+    bank, msgs = _bank(rng, sample_rate, n_bank, n_icao, df17_fraction)
+    L = bank.shape[1]
+    nframes = int(frames_per_sec * nsamples / sample_rate)
+    gap = int(150e-6 * sample_rate)
+    mean_step = nsamples / max(nframes, 1)
+    steps = L + gap + rng.exponential(max(mean_step - L - gap, 1.0), size=nframes).astype(np.int64)
+    pos = np.cumsum(steps) - steps[0] + rng.integers(0, gap)
+    pos = pos[pos + L < nsamples]
+    n_over = int(len(pos) * overlap_fraction)
+    if n_over:
+        base = rng.choice(pos, size=n_over, replace=False)
+        extra = base + rng.integers(20, L, size=n_over)
+        pos = np.sort(np.concatenate([pos, extra[extra + L < nsamples]]))
+    nf = len(pos)
+    which = rng.integers(0, n_bank, size=nf)
+    amp = 10 ** (rng.uniform(min_amp_db, max_amp_db, size=nf) / 20.0)
+    phi = rng.uniform(0, 2 * np.pi, size=nf)
+
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    bank_t = torch.from_numpy(bank).to(dev)
+    out = torch.empty(2 * nsamples, dtype=torch.uint8 if fmt == "uc8" else torch.int16, device=dev)
+    ar = torch.arange(L, device=dev)
+    for c0 in range(0, nsamples, chunk):
+        c1 = min(c0 + chunk, nsamples)
+        n = c1 - c0
+        x = torch.randn(2, n + L, generator=gen, device=dev, dtype=torch.float32) * noise_sigma
+        x[0] += dc_offset[0]
+        x[1] += dc_offset[1]
+        # frames that start inside [c0 - L, c1): the part falling in this chunk is added
+        lo, hi = np.searchsorted(pos, c0 - L, side="left"), np.searchsorted(pos, c1, side="left")
+        if hi > lo:
+            p = torch.from_numpy(pos[lo:hi] - c0).to(dev)
+            w = torch.from_numpy(which[lo:hi]).to(dev)
+            a = torch.from_numpy(amp[lo:hi].astype(np.float32)).to(dev)
+            ph = torch.from_numpy(phi[lo:hi].astype(np.float32)).to(dev)
+            idx = p[:, None] + ar[None, :]
+            env = bank_t[w] * a[:, None]
+            ok = (idx >= 0) & (idx < n)
+            idx = idx.clamp(0, n + L - 1)
+            x[0].index_put_((idx[ok],), (env * torch.cos(ph)[:, None])[ok], accumulate=True)
+            x[1].index_put_((idx[ok],), (env * torch.sin(ph)[:, None])[ok], accumulate=True)
+        iq = x[:, :n].t().contiguous().view(-1)                  # interleave I,Q
+        if fmt == "uc8":
+            q = torch.clamp(torch.round(iq * 127.5 + 127.5), 0, 255).to(torch.uint8)
+        elif fmt == "sc16":
+            q = torch.clamp(torch.round(iq * 32767.0), -32768, 32767).to(torch.int16)
+        else:
+            q = torch.clamp(torch.round(iq * 2047.0), -2048, 2047).to(torch.int16)
+        out[2 * c0:2 * c1] = q
+        del x, iq, q
+    return out, {"pos": pos, "which": which, "msgs": msgs, "amp": amp}

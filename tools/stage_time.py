@@ -1,0 +1,14 @@
+import os, sys, torch
+sys.path.insert(0, '.')
+import dump1090_amd as da
+from dump1090_amd import synth_torch
+fmt = sys.argv[1]
+n = (1<<30)//(2 if fmt=='uc8' else 4)
+iq, info = synth_torch.capture_gpu(n, 2.4e6, fmt, seed=1, device='cuda:0')
+e = da.Engine(2400000, da.INPUT_UC8 if fmt=='uc8' else da.INPUT_SC16)
+nb = iq.numel()*iq.element_size()
+for stop in (1,2,3,0):
+    os.environ['MODES_DEBUG_STOP'] = str(stop)
+    e.time_scan(iq.data_ptr(), nb, reps=2)
+    ms = e.time_scan(iq.data_ptr(), nb, reps=5)
+    print(fmt, "stop", stop, "ms %.3f" % ms, "Gsamples/s %.1f" % (n/ms/1e6))
