@@ -58,6 +58,30 @@ MagBuf._fields_ = [("data", C.POINTER(C.c_uint16)), ("total_length", C.c_uint), 
 CONVERT_FUNC = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_uint, C.POINTER(ConvertState), C.POINTER(C.c_double))
 
 
+class ErrorInfo(C.Structure):
+    _fields_ = [("syndrome", C.c_uint32), ("errors", C.c_int), ("bit", C.c_int8 * 2)]
+
+
+SCORE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int)
+DECODE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+DECODE_A_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int)
+USER_CB = C.CFUNCTYPE(None, C.c_void_p)
+LEN_CB = C.CFUNCTYPE(C.c_int, C.c_int)
+CLOCK_CB = C.CFUNCTYPE(C.c_int64, C.c_uint64, C.c_uint64)
+
+
+class HostBinding(C.Structure):
+    """modes_hip_host (include/modes_hip.h, Part 2)."""
+    _fields_ = [("mm_size", C.c_size_t), ("off_timestamp_msg", C.c_size_t), ("off_sys_timestamp_msg", C.c_size_t),
+                ("off_sig_level", C.c_size_t), ("off_score", C.c_size_t), ("off_error_bits", C.c_size_t),
+                ("off_AC_flags", C.c_size_t), ("off_addr", C.c_size_t),
+                ("modeS_message_score", SCORE_CB), ("decode_mode_S_message", DECODE_CB),
+                ("decode_mode_A_message", DECODE_A_CB), ("modeS_user_message", USER_CB),
+                ("modeS_message_len_by_type", LEN_CB), ("receiveclock_ms_elapsed", CLOCK_CB),
+                ("phase_enhance", C.c_int), ("mode_AC", C.c_int), ("measure_noise", C.c_int), ("fix_bits", C.c_int),
+                ("device", C.c_int)]
+
+
 class ModesError(RuntimeError):
     pass
 
@@ -96,6 +120,23 @@ def lib():
         L.modes_engine_tail_halo.argtypes = [C.c_void_p]
         L.modes_convert_device.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(ConvertState),
                                            C.POINTER(C.c_double), C.c_void_p]
+        L.modes_hip_bind.argtypes = [C.c_void_p]
+        L.convert_init.restype = C.c_void_p
+        L.convert_init.argtypes = [C.c_int, C.c_double, C.c_bool, C.c_bool, C.POINTER(C.POINTER(ConvertState))]
+        L.convert_cleanup.argtypes = [C.POINTER(C.POINTER(ConvertState))]
+        L.convert_format_name.restype = C.c_char_p
+        L.convert_format_name.argtypes = [C.c_int]
+        for n in ("demod_2000", "demod_2400", "demod_2400_AC", "demod_8000"):
+            getattr(L, n).argtypes = [C.POINTER(MagBuf)]
+            getattr(L, n).restype = None
+        L.crc_init.argtypes = [C.c_int]
+        L.crc_checksum.restype = C.c_uint32
+        L.crc_checksum.argtypes = [C.c_void_p, C.c_int]
+        L.crc_checksum_diagnose.restype = C.POINTER(ErrorInfo)
+        L.crc_checksum_diagnose.argtypes = [C.c_uint32, C.c_int]
+        L.crc_checksum_fix.argtypes = [C.c_void_p, C.POINTER(ErrorInfo)]
+        L.modes_hip_take_messages.restype = C.c_size_t
+        L.modes_hip_take_messages.argtypes = [C.c_void_p, C.c_size_t]
         _lib = L
     return _lib
 
@@ -177,3 +218,51 @@ def convert_device(conv_id, d_iq_ptr, d_mag_ptr, nsamples, state=None, want_powe
 
 def msg_hex(rec):
     return bytes(rec["msg"][: int(rec["msg_bits"]) // 8]).hex()
+
+
+# ---- the reference's own entry points (Part 1), host buffers ------------------------------------
+
+class Converter:
+    """convert_init() / convert_func / convert_cleanup() (ref: src/convert.h:28-42)."""
+
+    def __init__(self, fmt, sample_rate, filter_dc, compute_power):
+        self.L = lib()
+        self.state = C.POINTER(ConvertState)()
+        fp = self.L.convert_init(fmt, float(sample_rate), bool(filter_dc), bool(compute_power), C.byref(self.state))
+        if not fp:
+            raise ModesError("convert_init returned NULL")
+        self.func = CONVERT_FUNC(fp)
+        self.name = self.state.contents.func_name.decode()
+
+    def __call__(self, iq, nsamples, want_power=True):
+        iq = np.ascontiguousarray(iq)
+        mag = np.zeros(nsamples, dtype=np.uint16)
+        p = C.c_double(-1.0)
+        self.func(iq.ctypes.data_as(C.c_void_p), mag.ctypes.data_as(C.c_void_p), nsamples, self.state,
+                  C.byref(p) if want_power else None)
+        return mag, p.value
+
+    def close(self):
+        if self.state:
+            self.L.convert_cleanup(C.byref(self.state))
+
+    __del__ = close
+
+
+def make_mag_buf(data, overlap, sample_timestamp=0, mean_power=0.0, total_length=None):
+    data = np.ascontiguousarray(data, dtype=np.uint16)
+    mb = MagBuf()
+    mb.data = data.ctypes.data_as(C.POINTER(C.c_uint16))
+    mb.total_length = total_length if total_length is not None else len(data)
+    mb.valid_length = len(data)
+    mb.overlap = overlap
+    mb.sample_timestamp = sample_timestamp
+    mb.mean_power = mean_power
+    mb._keep = data
+    return mb
+
+
+def take_messages(max_n=1 << 20):
+    buf = np.zeros(max_n, dtype=MESSAGE_DTYPE)
+    n = lib().modes_hip_take_messages(buf.ctypes.data_as(C.c_void_p), max_n)
+    return buf[:n].copy()

@@ -12,7 +12,8 @@ constexpr uint32_t kNonIcao = 1u << 24;              // ref: src/misc.h:699
 // Converter rows of converters_table[] (ref: src/convert.c:301-308)
 enum Conv : int {
   kConvUc8Lut = 0, kConvUc8LutPower = 1, kConvUc8Generic = 2,
-  kConvSc16Int = 3, kConvSc16Generic = 4, kConvSc16Q11Generic = 5
+  kConvSc16Int = 3, kConvSc16Generic = 4, kConvSc16Q11Generic = 5,
+  kConvMagU16 = 6     // not a converter: the input already is the uint16 magnitude buffer of a mag_buf
 };
 
 // ---- scan kernel geometry (2.4 MS/s) -------------------------------------------------
@@ -54,6 +55,7 @@ static_assert(sizeof(ErrEntry) == 8, "ErrEntry must be 8 bytes");
 struct ScanParams {
   const uint8_t  *iq;          // device, whole shard
   uint64_t        nsamples;    // samples in the shard == scan positions
+  uint64_t        navail;      // kConvMagU16 only: valid magnitudes in `iq` (mag_buf.valid_length)
   const uint16_t *halo;        // `ov` magnitudes that precede sample 0, or nullptr (zeros)
   uint32_t        ov;          // Modes.trailing_samples (ref: src/dump1090.c:734)
   uint32_t        block_samples;

@@ -20,8 +20,11 @@
 using namespace modes;
 
 namespace {
-
 thread_local std::string g_err;
+}
+
+namespace {
+
 
 int fail (int code, const char *fmt, ...)
 {
@@ -33,6 +36,24 @@ int fail (int code, const char *fmt, ...)
   g_err = buf;
   return code;
 }
+
+}  // namespace
+
+namespace modes {
+// error reporting shared with dropin.cpp
+int set_error (int code, const char *fmt, ...)
+{
+  char buf[512];
+  va_list ap;
+  va_start (ap, fmt);
+  vsnprintf (buf, sizeof buf, fmt, ap);
+  va_end (ap);
+  g_err = buf;
+  return code;
+}
+}  // namespace modes
+
+namespace {
 
 #define HIP_TRY(expr)                                                                          \
   do {                                                                                         \

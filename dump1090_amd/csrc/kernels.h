@@ -11,6 +11,8 @@ hipError_t launch_convert (int conv, const uint8_t *iq, uint16_t *mag, size_t n,
 hipError_t launch_rssi2400 (int conv, const uint8_t *iq, uint64_t nsamples, const uint16_t *halo, uint32_t ov,
                             uint32_t block_samples, const uint16_t *lut256, const uint64_t *pos, const uint32_t *len,
                             uint64_t *sum_out, uint32_t nmsg, hipStream_t stream);
+hipError_t launch_convert_float (int conv, const uint8_t *iq, uint16_t *mag, size_t n, float A, float B, float zI0, float zQ0,
+                                 float *zI, float *zQ, float *mag_sq, float *z_final, float *power_out, hipStream_t stream);
 hipError_t launch_count_scan (const uint32_t *counts, const uint32_t *vp_counts, uint32_t nstrips, uint64_t *chunk_sum,
                               uint64_t *chunk_vp, uint64_t *chunk_ovf, uint64_t *totals, hipStream_t stream);
 hipError_t launch_gather (const uint32_t *counts, uint32_t nstrips, const uint64_t *chunk_sum, const Record *records,

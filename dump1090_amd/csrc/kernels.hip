@@ -160,7 +160,7 @@ constexpr int kWavesPerBlock = 4;
 // ------------------------------------------------------------------------------------------
 // staging: convert samples [a_lo, a_lo + count) into w.tile[0 .. count)
 // ------------------------------------------------------------------------------------------
-template <int CONV> struct RawWords { static constexpr int n = (CONV == kConvUc8Lut || CONV == kConvUc8LutPower) ? 2 : (CONV == kConvUc8Generic) ? 4 : 8; };
+template <int CONV> struct RawWords { static constexpr int n = (CONV == kConvUc8Lut || CONV == kConvUc8LutPower) ? 2 : (CONV == kConvUc8Generic || CONV == kConvMagU16) ? 4 : 8; };
 
 // raw IQ of 8 consecutive samples starting at n0 (a multiple of 8, whole chunk inside the shard)
 template <int CONV>
@@ -171,7 +171,7 @@ __device__ __forceinline__ void load_raw8 (const ScanParams &p, long long n0, ui
     const uint64_t blk = uint64_t (n0) / p.block_samples, i = uint64_t (n0) % p.block_samples;
     const uint2 v = *reinterpret_cast<const uint2 *> (p.iq + blk * 2 * p.block_samples + i);
     d[0] = v.x; d[1] = v.y;
-  } else if (CONV == kConvUc8Generic) {
+  } else if (CONV == kConvUc8Generic || CONV == kConvMagU16) {
     const uint4 v = *reinterpret_cast<const uint4 *> (p.iq + 2 * n0);
     d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
   } else {
@@ -184,6 +184,7 @@ __device__ __forceinline__ void load_raw8 (const ScanParams &p, long long n0, ui
 template <int CONV>
 __device__ __forceinline__ uint4 convert_raw8 (const WaveLds &w, const uint32_t *d)
 {
+  if (CONV == kConvMagU16) { uint4 pk; pk.x = d[0]; pk.y = d[1]; pk.z = d[2]; pk.w = d[3]; return pk; }
   uint16_t out[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) {
@@ -214,7 +215,7 @@ constexpr int kTileIters = (kTileChunks + 63) / 64;
 template <int CONV>
 __device__ __forceinline__ void stage_tile (WaveLds &w, const ScanParams &p, long long a_lo, int lane)
 {
-  const long long N = (long long) p.nsamples;
+  const long long N = (long long) (CONV == kConvMagU16 ? p.navail : p.nsamples);
   constexpr int NW = RawWords<CONV>::n;
   if (a_lo >= 0 && a_lo + kTileCount <= N) {
     // interior strip: every load is issued before the first conversion
@@ -248,7 +249,8 @@ __device__ __forceinline__ void stage_tile (WaveLds &w, const ScanParams &p, lon
         if (n < 0) {
           if (p.halo && n + (long long) p.ov >= 0) m = p.halo[n + (long long) p.ov];
         } else if (n < N) {
-          if (CONV == kConvUc8Lut || CONV == kConvUc8LutPower) {
+          if (CONV == kConvMagU16) m = reinterpret_cast<const uint16_t *> (p.iq)[n];
+          else if (CONV == kConvUc8Lut || CONV == kConvUc8LutPower) {
             const uint64_t blk = uint64_t (n) / p.block_samples, i = uint64_t (n) % p.block_samples;
             m = w.lut[p.iq[blk * 2 * p.block_samples + i]];
           } else if (CONV == kConvUc8Generic) {
@@ -292,7 +294,7 @@ void scan2400_kernel (const ScanParams p)
 
   // ---- stage A: magnitudes of V[P0 .. P0 + kStrip + kLook2400) into LDS ----
   const long long P0 = (long long) strip * kStrip;
-  const long long s0 = P0 - (long long) p.ov;                 // first sample index needed (may be < 0)
+  const long long s0 = P0 - (long long) (CONV == kConvMagU16 ? 0u : p.ov);   // first sample index needed (may be < 0)
   const long long a_lo = (s0 >= 0 ? s0 : s0 - 15) / 16 * 16;  // floor to a multiple of 16
   const int shift = int (s0 - a_lo);                          // V[P0 + x] == tile[x + shift]
   stage_tile<CONV> (w, p, a_lo, lane);
@@ -570,6 +572,7 @@ template <int CONV>
 __device__ __forceinline__ uint16_t mag_of_V (const uint8_t *iq, uint64_t nsamples, const uint16_t *halo, uint32_t ov,
                                               uint32_t block_samples, const uint16_t *lut256, long long x)
 {
+  if (CONV == kConvMagU16) return (x >= 0 && uint64_t (x) < nsamples) ? reinterpret_cast<const uint16_t *> (iq)[x] : uint16_t (0);
   const long long n = x - (long long) ov;
   if (n < 0) return (halo && x >= 0) ? halo[x] : uint16_t (0);
   if (uint64_t (n) >= nsamples) return 0;
@@ -691,6 +694,108 @@ void gather_kernel (const uint32_t *counts, uint32_t nstrips, const uint64_t *ch
   for (uint32_t i = lane; i < cnt; i += 64) packed_pos[off + i] = uint64_t (strip) * kStrip + records[size_t (strip) * cap + i].off;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// float converters with the DC block on (ref: src/convert.c:112-245).  The one-pole filter
+// z1 = f*DC_A + z1*DC_B is evaluated in the reference's order, one rounding per operation:
+//   dc_zscan_kernel : one wave; all lanes stage f*DC_A into LDS, lanes 0/1 run the I and Q chains
+//   dc_mag_kernel   : wide; magnitude (and mag_sq) from the stored z1 sequences
+//   power_seq_kernel: one lane adds mag_sq in sample order (float, like `power += mag_sq`)
+// ------------------------------------------------------------------------------------------
+template <int CONV>
+__device__ __forceinline__ void sample_to_float (const uint8_t *iq, size_t i, float *fI, float *fQ)
+{
+  if (CONV == kConvUc8Generic) { *fI = c_uc8_float[iq[2 * i]]; *fQ = c_uc8_float[iq[2 * i + 1]]; }
+  else {
+    const int16_t *s = reinterpret_cast<const int16_t *> (iq) + 2 * i;
+    const float sc = CONV == kConvSc16Generic ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
+    *fI = float (s[0]) * sc; *fQ = float (s[1]) * sc;
+  }
+}
+
+constexpr int kZChunk = 2048;
+
+template <int CONV>
+__global__ __launch_bounds__ (64)
+void dc_zscan_kernel (const uint8_t *iq, size_t n, float A, float B, float zI0, float zQ0, float *zI, float *zQ, float *z_final)
+{
+  __shared__ float c[2][kZChunk];
+  const int lane = threadIdx.x;
+  float z = lane == 0 ? zI0 : zQ0;
+  for (size_t base = 0; base < n; base += kZChunk) {
+    const int cnt = int (n - base < size_t (kZChunk) ? n - base : size_t (kZChunk));
+    for (int i = lane; i < cnt; i += 64) {
+      float fI, fQ;
+      sample_to_float<CONV> (iq, base + i, &fI, &fQ);
+      c[0][i] = __fmul_rn (fI, A);
+      c[1][i] = __fmul_rn (fQ, A);
+    }
+    __syncthreads ();
+    if (lane < 2) {
+      float *cc = c[lane];
+      int i = 0;
+      for (; i + 4 <= cnt; i += 4) {
+        const float4 v = *reinterpret_cast<const float4 *> (cc + i);
+        float4 o;
+        z = __fadd_rn (v.x, __fmul_rn (z, B)); o.x = z;
+        z = __fadd_rn (v.y, __fmul_rn (z, B)); o.y = z;
+        z = __fadd_rn (v.z, __fmul_rn (z, B)); o.z = z;
+        z = __fadd_rn (v.w, __fmul_rn (z, B)); o.w = z;
+        *reinterpret_cast<float4 *> (cc + i) = o;
+      }
+      for (; i < cnt; i++) { z = __fadd_rn (cc[i], __fmul_rn (z, B)); cc[i] = z; }
+    }
+    __syncthreads ();
+    for (int i = lane; i < cnt; i += 64) { zI[base + i] = c[0][i]; zQ[base + i] = c[1][i]; }
+    __syncthreads ();
+  }
+  if (lane < 2) z_final[lane] = z;
+}
+
+template <int CONV>
+__global__ __launch_bounds__ (256)
+void dc_mag_kernel (const uint8_t *iq, size_t n, const float *zI, const float *zQ, uint16_t *mag, float *mag_sq)
+{
+  const size_t stride = size_t (gridDim.x) * blockDim.x;
+  for (size_t i = size_t (blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float fI, fQ, sq;
+    sample_to_float<CONV> (iq, i, &fI, &fQ);
+    fI = __fsub_rn (fI, zI[i]);
+    fQ = __fsub_rn (fQ, zQ[i]);
+    mag[i] = mag_from_float (fI, fQ, &sq);
+    if (mag_sq) mag_sq[i] = sq;
+  }
+}
+
+// stateless variant of the same converters (DC_A = 0, DC_B = 1: z1 stays 0) that also stores mag_sq
+template <int CONV>
+__global__ __launch_bounds__ (256)
+void nodc_mag_kernel (const uint8_t *iq, size_t n, uint16_t *mag, float *mag_sq)
+{
+  const size_t stride = size_t (gridDim.x) * blockDim.x;
+  for (size_t i = size_t (blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float fI, fQ, sq;
+    sample_to_float<CONV> (iq, i, &fI, &fQ);
+    mag[i] = mag_from_float (fI, fQ, &sq);
+    if (mag_sq) mag_sq[i] = sq;
+  }
+}
+
+__global__ __launch_bounds__ (64)
+void power_seq_kernel (const float *mag_sq, size_t n, float *out)
+{
+  if (threadIdx.x != 0) return;
+  float p = 0.0f;
+  size_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    const float4 a = *reinterpret_cast<const float4 *> (mag_sq + i), b = *reinterpret_cast<const float4 *> (mag_sq + i + 4);
+    p = __fadd_rn (p, a.x); p = __fadd_rn (p, a.y); p = __fadd_rn (p, a.z); p = __fadd_rn (p, a.w);
+    p = __fadd_rn (p, b.x); p = __fadd_rn (p, b.y); p = __fadd_rn (p, b.z); p = __fadd_rn (p, b.w);
+  }
+  for (; i < n; i++) p = __fadd_rn (p, mag_sq[i]);
+  *out = p;
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers (called from engine.cpp)
 // ------------------------------------------------------------------------------------------
@@ -712,6 +817,7 @@ hipError_t launch_scan2400 (const ScanParams &p, hipStream_t stream)
     case kConvSc16Int:        hipLaunchKernelGGL (scan2400_kernel<kConvSc16Int>, grid, block, 0, stream, p); break;
     case kConvSc16Generic:    hipLaunchKernelGGL (scan2400_kernel<kConvSc16Generic>, grid, block, 0, stream, p); break;
     case kConvSc16Q11Generic: hipLaunchKernelGGL (scan2400_kernel<kConvSc16Q11Generic>, grid, block, 0, stream, p); break;
+    case kConvMagU16:         hipLaunchKernelGGL (scan2400_kernel<kConvMagU16>, grid, block, 0, stream, p); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError ();
@@ -774,6 +880,32 @@ hipError_t launch_gather (const uint32_t *counts, uint32_t nstrips, const uint64
   if (nstrips == 0) return hipSuccess;
   hipLaunchKernelGGL (gather_kernel, dim3 ((nstrips + 3) / 4), dim3 (256), 0, stream, counts, nstrips, chunk_sum, records,
                       cap, packed, packed_pos, offsets);
+  return hipGetLastError ();
+}
+
+// Float converter with explicit DC-block state (one convert_func call).  zI/zQ/mag_sq are n-float scratch
+// buffers; z_io[2] holds z1_I, z1_Q on entry and exit (device memory); power_out (device, 1 float) may be null.
+hipError_t launch_convert_float (int conv, const uint8_t *iq, uint16_t *mag, size_t n, float A, float B, float zI0, float zQ0,
+                                 float *zI, float *zQ, float *mag_sq, float *z_final, float *power_out, hipStream_t stream)
+{
+  if (n == 0) return hipSuccess;
+  const size_t want = (n + 255) / 256;
+  const dim3 grid ((unsigned) (want < 16384 ? want : 16384)), block (256);
+  const bool dc = !(A == 0.0f && B == 1.0f);
+#define FLOATCONV(C)                                                                                                     \
+  if (dc) {                                                                                                               \
+    hipLaunchKernelGGL (dc_zscan_kernel<C>, dim3 (1), dim3 (64), 0, stream, iq, n, A, B, zI0, zQ0, zI, zQ, z_final);      \
+    hipLaunchKernelGGL (dc_mag_kernel<C>, grid, block, 0, stream, iq, n, zI, zQ, mag, power_out ? mag_sq : nullptr);      \
+  } else                                                                                                                  \
+    hipLaunchKernelGGL (nodc_mag_kernel<C>, grid, block, 0, stream, iq, n, mag, power_out ? mag_sq : nullptr)
+  switch (conv) {
+    case kConvUc8Generic:     FLOATCONV (kConvUc8Generic); break;
+    case kConvSc16Generic:    FLOATCONV (kConvSc16Generic); break;
+    case kConvSc16Q11Generic: FLOATCONV (kConvSc16Q11Generic); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef FLOATCONV
+  if (power_out) hipLaunchKernelGGL (power_seq_kernel, dim3 (1), dim3 (64), 0, stream, mag_sq, n, power_out);
   return hipGetLastError ();
 }
 

@@ -22,6 +22,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden */
+#endif
 
 /* ===================================================================================== */
 /* Part 1 -- the reference's interface for this path                                      */
@@ -229,6 +232,9 @@ int  modes_convert_device (int converter_id /* row of converters_table, ref: src
 /* messages queued by the drop-in demod_*() when no modeS_user_message callback is bound */
 size_t modes_hip_take_messages (modes_message *out, size_t max);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif
