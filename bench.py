@@ -62,10 +62,12 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
+        eng.set_icao(None)                    # every step decodes the recording from a cold ICAO cache
         eng.run_device(iq.data_ptr(), nbytes, stream=stream)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        eng.set_icao(None)
         eng.run_device(iq.data_ptr(), nbytes, stream=stream)
     barrier()
     dt = time.perf_counter() - t0

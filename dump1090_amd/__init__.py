@@ -150,7 +150,7 @@ class Engine:
     """Bulk engine (Part 3 of include/modes_hip.h)."""
 
     def __init__(self, sample_rate=2400000, input_format=INPUT_UC8, filter_dc=False, compute_power=False, fix_bits=1,
-                 phase_enhance=False, mode_ac=False, device=0, host_replay=True):
+                 phase_enhance=False, mode_ac=False, device=0, host_replay=False):
         self.L = lib()
         cfg = EngineConfig(sample_rate=sample_rate, input_format=input_format, filter_dc=int(filter_dc),
                            compute_power=int(compute_power), fix_bits=fix_bits, phase_enhance=int(phase_enhance),

@@ -76,3 +76,36 @@ struct ScanParams {
 };
 
 }  // namespace modes
+
+namespace modes {
+
+// ---- ordered accept pass on the device ------------------------------------------------------
+constexpr uint32_t kDeltaWritten = 0x80000000u;   // marks an ICAO slot a block wrote (addresses use 25 bits)
+
+enum BlkStat : int { kStDemodulated = 0, kStOutOfPhase, kStGood, kStBad, kStFix1, kStFix2, kStUnknown, kStSkippedVp, kStAccepted, kBlkStats = 12 };
+
+struct AcceptParams {
+  Record         *records;       // [nstrips][cap]; flags/score are written back
+  const uint32_t *counts;        // [nstrips]
+  uint32_t        cap, nstrips, strips_per_block, nblocks;
+  uint64_t        nsamples;
+  uint32_t        block_samples;
+  const uint32_t *snap_in;       // [nblocks][1024] ICAO cache at the start of each block
+  uint32_t       *delta;         // [nblocks][1024] kDeltaWritten | address for the slots the block wrote
+  uint32_t       *acc_counts;    // [nstrips] accepted messages per strip
+  uint32_t       *blk_stats;     // [nblocks][kBlkStats]
+  const uint64_t *vp_bitmap;     // may be null
+  uint32_t       *changed;       // set to 1 when a delta entry differs from the previous round
+};
+
+struct EmitParams {
+  const Record   *records; const uint32_t *counts; const uint32_t *acc_counts; const uint64_t *chunk_sum;   // exclusive scan of acc_counts per 1024-strip chunk
+  uint32_t        cap, nstrips;
+  // stream geometry for timestamps and the signal level
+  const uint8_t  *iq; uint64_t nsamples, navail; const uint16_t *halo; uint32_t ov, block_samples; int32_t conv;
+  const uint16_t *lut256;
+  uint64_t        first_sample; uint32_t sample_rate;
+  void           *messages;      // modes_message[total]
+};
+
+}  // namespace modes

@@ -122,7 +122,8 @@ struct modes_engine {
   IcaoCache cache;
   // device buffers
   DevBuf<Record> records, packed;
-  DevBuf<uint32_t> counts, vp_counts, rssi_len;
+  DevBuf<uint32_t> counts, vp_counts, rssi_len, snap_in, delta, chunk_last, chunk_entry, acc_counts, blk_stats, small_u32;
+  DevBuf<modes_message> d_messages;
   DevBuf<uint64_t> chunk_sum, chunk_vp, chunk_ovf, packed_pos, offsets, rssi_pos, rssi_sum, vp_bitmap;
   DevBuf<uint8_t> staging;                  // for run_host
   DevBuf<uint16_t> tail;
@@ -200,6 +201,87 @@ int fill_scan_params (modes_engine *e, const void *d_iq, size_t nbytes, const ui
   return MODES_OK;
 }
 
+
+// The ordered accept pass on the device: fixed-point rounds over the per-block ICAO snapshots, then emit.
+int run_accept_on_device (modes_engine *e, const ScanParams &sp, uint64_t first_sample, hipStream_t stream)
+{
+  const uint32_t B = e->block_samples;
+  const uint32_t nblocks = uint32_t ((sp.nsamples + B - 1) / B);
+  const uint32_t nchunks = (nblocks + 31) / 32;
+  int rc;
+  if ((rc = e->snap_in.reserve (size_t (nblocks) * kIcaoSlots)) != MODES_OK) return rc;
+  if ((rc = e->delta.reserve (size_t (nblocks) * kIcaoSlots)) != MODES_OK) return rc;
+  if ((rc = e->chunk_last.reserve (size_t (nchunks + 1) * kIcaoSlots)) != MODES_OK) return rc;
+  if ((rc = e->chunk_entry.reserve (size_t (nchunks + 1) * kIcaoSlots)) != MODES_OK) return rc;
+  if ((rc = e->acc_counts.reserve (sp.nstrips)) != MODES_OK) return rc;
+  if ((rc = e->blk_stats.reserve (size_t (nblocks) * kBlkStats)) != MODES_OK) return rc;
+  if ((rc = e->small_u32.reserve (2 * kIcaoSlots + 16)) != MODES_OK) return rc;
+  uint32_t *d_cache_in = e->small_u32.p, *d_cache_out = e->small_u32.p + kIcaoSlots, *d_changed = e->small_u32.p + 2 * kIcaoSlots;
+
+  HIP_TRY (hipMemcpyAsync (d_cache_in, e->cache.raw (), kIcaoSlots * sizeof (uint32_t), hipMemcpyHostToDevice, stream));
+  HIP_TRY (hipMemsetAsync (e->delta.p, 0, size_t (nblocks) * kIcaoSlots * sizeof (uint32_t), stream));
+  HIP_TRY (hipMemsetAsync (e->acc_counts.p, 0, size_t (sp.nstrips) * sizeof (uint32_t), stream));
+  HIP_TRY (launch_snap_broadcast (d_cache_in, nblocks, e->snap_in.p, stream));
+
+  AcceptParams ap;
+  memset (&ap, 0, sizeof ap);
+  ap.records = e->records.p; ap.counts = e->counts.p; ap.cap = e->cap; ap.nstrips = sp.nstrips;
+  ap.strips_per_block = B / kStrip; ap.nblocks = nblocks; ap.nsamples = sp.nsamples; ap.block_samples = B;
+  ap.snap_in = e->snap_in.p; ap.delta = e->delta.p; ap.acc_counts = e->acc_counts.p; ap.blk_stats = e->blk_stats.p;
+  ap.vp_bitmap = e->vp_bitmap.p; ap.changed = d_changed;
+
+  uint32_t rounds = 0;
+  for (;;) {
+    uint32_t changed = 0;
+    HIP_TRY (hipMemsetAsync (d_changed, 0, sizeof (uint32_t), stream));
+    HIP_TRY (launch_accept2400 (ap, stream));
+    HIP_TRY (hipMemcpyAsync (&changed, d_changed, sizeof changed, hipMemcpyDeviceToHost, stream));
+    HIP_TRY (hipStreamSynchronize (stream));
+    rounds++;
+    HIP_TRY (launch_snapshots (e->delta.p, nblocks, d_cache_in, e->chunk_last.p, e->chunk_entry.p, e->snap_in.p, d_cache_out, stream));
+    if (!changed) break;
+    if (rounds > 256) return fail (MODES_E_HIP, "accept pass did not reach its fixed point in 256 rounds");
+  }
+  e->stats.replay_rounds = rounds;
+
+  // totals of accepted messages, then emit in order
+  uint64_t *d_totals = reinterpret_cast<uint64_t *> (e->d_stats);
+  HIP_TRY (launch_count_scan (e->acc_counts.p, e->vp_counts.p, sp.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p, d_totals, stream));
+  unsigned long long tot[3];
+  std::vector<uint32_t> bst (size_t (nblocks) * kBlkStats);
+  HIP_TRY (hipMemcpyAsync (tot, d_totals, sizeof tot, hipMemcpyDeviceToHost, stream));
+  HIP_TRY (hipMemcpyAsync (bst.data (), e->blk_stats.p, bst.size () * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
+  HIP_TRY (hipMemcpyAsync (e->cache.raw (), d_cache_out, kIcaoSlots * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
+  HIP_TRY (hipStreamSynchronize (stream));
+  const size_t nm = size_t (tot[0]);
+  uint64_t sum[kBlkStats] = { 0 };
+  for (uint32_t b = 0; b < nblocks; b++) for (int k = 0; k < kBlkStats; k++) sum[k] += bst[size_t (b) * kBlkStats + k];
+  e->stats.demodulated = sum[kStDemodulated]; e->stats.out_of_phase = sum[kStOutOfPhase];
+  e->stats.CRC_good = sum[kStGood]; e->stats.CRC_bad = sum[kStBad];
+  e->stats.CRC_single_bit_fix = sum[kStFix1]; e->stats.CRC_two_bits_fix = sum[kStFix2];
+  e->stats.CRC_fixed = sum[kStFix1] + sum[kStFix2];
+  e->stats.demod_rejected_unknown = sum[kStUnknown];
+  e->stats.valid_preamble -= sum[kStSkippedVp];
+  if (sum[kStAccepted] != nm) return fail (MODES_E_HIP, "accepted-count mismatch (%llu vs %zu)", (unsigned long long) sum[kStAccepted], nm);
+
+  e->messages.resize (nm);
+  if (nm) {
+    if ((rc = e->d_messages.reserve (nm)) != MODES_OK) return rc;
+    EmitParams ep;
+    memset (&ep, 0, sizeof ep);
+    ep.records = e->records.p; ep.counts = e->counts.p; ep.acc_counts = e->acc_counts.p; ep.chunk_sum = e->chunk_sum.p;
+    ep.cap = e->cap; ep.nstrips = sp.nstrips;
+    ep.iq = sp.iq; ep.nsamples = sp.nsamples; ep.navail = sp.navail; ep.halo = sp.halo; ep.ov = sp.ov;
+    ep.block_samples = sp.block_samples; ep.conv = sp.conv; ep.lut256 = sp.lut256;
+    ep.first_sample = first_sample; ep.sample_rate = e->cfg.sample_rate;
+    ep.messages = e->d_messages.p;
+    HIP_TRY (launch_emit2400 (ep, stream));
+    HIP_TRY (hipMemcpyAsync (e->messages.data (), e->d_messages.p, nm * sizeof (modes_message), hipMemcpyDeviceToHost, stream));
+    HIP_TRY (hipStreamSynchronize (stream));
+  }
+  return MODES_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -241,6 +323,8 @@ void modes_engine_destroy (modes_engine *e)
   if (!e) return;
   e->records.release (); e->packed.release (); e->counts.release (); e->rssi_len.release ();
   e->chunk_sum.release (); e->chunk_vp.release (); e->chunk_ovf.release (); e->vp_counts.release (); e->packed_pos.release (); e->offsets.release (); e->rssi_pos.release ();
+  e->snap_in.release (); e->delta.release (); e->chunk_last.release (); e->chunk_entry.release (); e->acc_counts.release ();
+  e->blk_stats.release (); e->small_u32.release (); e->d_messages.release ();
   e->rssi_sum.release (); e->staging.release (); e->tail.release (); e->vp_bitmap.release ();
   if (e->tabs.short_tab) (void) hipFree (e->tabs.short_tab);
   if (e->tabs.long_tab) (void) hipFree (e->tabs.long_tab);
@@ -298,6 +382,10 @@ int modes_engine_run_device (modes_engine *e, const void *d_iq, size_t nbytes, u
   const size_t nrec = size_t (st[0]);
   e->stats.valid_preamble = st[1];
   e->stats.candidates = nrec;
+
+  if (!e->cfg.host_replay && !e->cfg.phase_enhance)
+    return run_accept_on_device (e, sp, first_sample, stream);
+
   if ((rc = e->packed.reserve (nrec + 1)) != MODES_OK) return rc;
   if ((rc = e->packed_pos.reserve (nrec + 1)) != MODES_OK) return rc;
   HIP_TRY (launch_gather (e->counts.p, sp.nstrips, e->chunk_sum.p, e->records.p, e->cap, e->packed.p, e->packed_pos.p,

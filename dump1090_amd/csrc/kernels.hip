@@ -796,6 +796,333 @@ void power_seq_kernel (const float *mag_sq, size_t n, float *out)
   *out = p;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Ordered accept pass on the device (what demod_2400's loop does with every candidate that
+// reached modeS_message_score: ICAO cache tests/updates, decode_mode_S_message's accept rules,
+// skip-ahead; ref: src/demod-2400.c:438-518, src/dump1090.c:2372-2578,2676-2687,3279-3365).
+//
+// One wave per 256 KiB block.  The wave keeps the block's running ICAO cache in LDS, seeded from
+// snap_in[block].  Blocks depend on each other only through that cache, so the host iterates:
+// accept -> propagate the per-block writes (delta) down the block axis -> accept again, until no
+// delta changes; decisions at a position depend only on earlier positions, so the fixed point is
+// the sequential result.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t icao_hash (uint32_t a)      // ref: src/dump1090.c:1438-1447
+{
+  a = ((a >> 16) ^ a) * 0x45D9F3Bu;
+  a = ((a >> 16) ^ a) * 0x45D9F3Bu;
+  a = (a >> 16) ^ a;
+  return a & (kIcaoSlots - 1);
+}
+
+// MODES_NON_ICAO_ADDRESS for DF17/18 (ref: src/dump1090.c:1918-1963,1990,2097,2130,2220,2239); m = message words, little endian
+__device__ __forceinline__ uint32_t non_icao_flag_dev (const uint8_t *msg, int df)
+{
+  bool look = false;
+  if (df == 18) {
+    const int cf = msg[0] & 7;
+    if (cf == 1 || cf == 5 || cf == 4 || cf == 7) return kNonIcao;
+    if (cf == 3) return (msg[4] & 0x80) ? kNonIcao : 0u;
+    look = cf == 2 || cf == 6;
+  }
+  if (!look) return 0;
+  const int type = msg[4] >> 3;
+  bool imf = false;
+  if (type == 19) imf = msg[5] & 0x80;
+  else if (type >= 5 && type <= 8) imf = msg[6] & 0x08;
+  else if (type == 0 || (type >= 9 && type <= 18) || (type >= 20 && type <= 22)) imf = msg[4] & 0x01;
+  else if (type == 28) imf = (msg[4] & 7) == 1 && (msg[10] & 0x01);
+  else if (type == 31) imf = msg[10] & 0x01;
+  return imf ? kNonIcao : 0u;
+}
+
+struct AcceptLds {
+  uint32_t cache[kIcaoSlots];
+  uint32_t written[kIcaoSlots / 32];
+  uint32_t counter[kBlkStats];
+};
+
+__device__ __forceinline__ uint32_t rdlane (uint32_t v, int l) { return uint32_t (__builtin_amdgcn_readlane (int (v), l)); }
+
+__global__ __launch_bounds__ (256)
+void accept2400_kernel (const AcceptParams p)
+{
+  __shared__ AcceptLds lds[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t blk = blockIdx.x * 4 + wv;
+  if (blk >= p.nblocks) return;
+  AcceptLds &w = lds[wv];
+  for (int i = lane; i < int (kIcaoSlots); i += 64) w.cache[i] = p.snap_in[size_t (blk) * kIcaoSlots + i];
+  if (lane < int (kIcaoSlots / 32)) w.written[lane] = 0;
+  if (lane < kBlkStats) w.counter[lane] = 0;
+  __builtin_amdgcn_s_waitcnt (0xc07f);
+  __builtin_amdgcn_wave_barrier ();
+
+  const uint32_t first_strip = blk * p.strips_per_block;
+  const uint32_t last_strip = min (first_strip + p.strips_per_block, p.nstrips);
+  const uint64_t blk_pos0 = uint64_t (blk) * p.block_samples;
+  const uint32_t blk_len = uint32_t (min (uint64_t (p.block_samples), p.nsamples - blk_pos0));
+  uint32_t skip_until = 0;                                   // each demod_2400 call starts at j = 0
+  uint32_t st_demod = 0, st_oop = 0, st_good = 0, st_bad = 0, st_fix1 = 0, st_fix2 = 0, st_unk = 0;
+
+  for (uint32_t strip = first_strip; strip < last_strip; strip++) {
+    const uint32_t cnt = p.counts[strip];
+    uint32_t nacc = 0;
+    for (uint32_t base = 0; base < cnt; base += 64) {
+      const bool have = base + lane < cnt;
+      Record *rp = p.records + size_t (strip) * p.cap + base + lane;
+      Record r;
+      if (have) { const uint4 *s4 = reinterpret_cast<const uint4 *> (rp); *reinterpret_cast<uint4 *> (&r) = s4[0]; *(reinterpret_cast<uint4 *> (&r) + 1) = s4[1]; }
+      else memset (&r, 0, sizeof r);
+      const uint32_t j = (strip - first_strip) * kStrip + r.off;
+      // --- per-record facts ---
+      uint32_t aa = (uint32_t (r.msg[1]) << 16) | (uint32_t (r.msg[2]) << 8) | r.msg[3];
+      bool aa_changed = false;
+      if (r.nerr >= 1 && r.bit0 >= 8 && r.bit0 <= 31) { aa ^= 1u << (31 - r.bit0); aa_changed = true; }
+      if (r.nerr >= 2 && r.bit1 >= 8 && r.bit1 <= 31) { aa ^= 1u << (31 - r.bit1); aa_changed = true; }
+      const bool ap = r.cls == kClsAP || r.cls == kClsAP2, acq = r.cls == kClsDF11;
+      const uint32_t iid = r.crc & 0x7F, masked = r.crc & 0xFFFF80u;
+      const uint32_t test_addr = ap ? r.crc : aa;
+      const uint32_t slot = icao_hash (test_addr);
+      bool uncond, need_known, adder;
+      if (ap)       { uncond = false; need_known = true; adder = false; }
+      else if (acq) { uncond = iid == 0 && masked == 0; need_known = !uncond; adder = uncond; }
+      else          { uncond = r.crc == 0 || (r.nerr == 1 && !aa_changed); need_known = !uncond; adder = r.crc == 0; }
+      uncond = uncond && have; need_known = need_known && have; adder = adder && have;
+      const uint32_t add_val = acq ? aa : (aa | non_icao_flag_dev (r.msg, r.df));
+      const uint32_t add_slot = icao_hash (add_val);
+      const uint32_t skip_len = uint32_t (msg_bits_for_df (r.df)) * 12 / 5;           // ref: src/demod-2400.c:514
+      const uint32_t c0 = w.cache[slot];
+      bool known = have && c0 != 0 && c0 == test_addr;
+
+      // --- which records can change anything: acceptable now, or their slot is written inside this batch ---
+      bool touched = false;
+      for (u64 am = __ballot (adder); am; am &= am - 1) {
+        const int a = __builtin_ctzll (am);
+        if (need_known && lane > a && slot == rdlane (add_slot, a)) touched = true;
+      }
+      u64 todo = __ballot (uncond || (need_known && known) || touched);
+      u64 accepted = 0;
+      uint32_t my_skip = 0;
+      const uint32_t skip_in = skip_until;
+      while (todo) {
+        const int i = __builtin_ctzll (todo);
+        todo &= todo - 1;
+        const uint32_t ji = rdlane (j, i);
+        if (ji < skip_until) continue;
+        const uint32_t ta = rdlane (test_addr, i), sl = rdlane (slot, i);
+        const uint32_t cur = w.cache[sl];
+        const bool kn = cur != 0 && cur == ta;
+        if (lane == i) known = kn;
+        const bool acc = ((__ballot (uncond) >> i) & 1) || kn;
+        if (!acc) continue;
+        accepted |= 1ull << i;
+        skip_until = ji + rdlane (skip_len, i) + 1;
+        if (lane == i) my_skip = skip_until;
+        if ((__ballot (adder) >> i) & 1) {                                            // ref: src/dump1090.c:2676-2687
+          const uint32_t as = rdlane (add_slot, i), av = rdlane (add_val, i);
+          if (lane == 0) { w.cache[as] = av; atomicOr (&w.written[as >> 5], 1u << (as & 31)); }
+          __builtin_amdgcn_s_waitcnt (0xc07f);
+          __builtin_amdgcn_wave_barrier ();
+        }
+      }
+      // --- what the reference would have counted for every record of the batch ---
+      const u64 before = accepted & ((1ull << lane) - 1);
+      uint32_t skip_at = skip_in;
+      {
+        const int prev = before ? 63 - __builtin_clzll (before) : 0;
+        const uint32_t v = uint32_t (__shfl (int (my_skip), prev, 64));
+        if (before) skip_at = v;
+      }
+      const bool reached = have && j >= skip_at;
+      int score;
+      if (ap)       score = known ? 1000 : (r.cls == kClsAP ? -1 : -2);
+      else if (acq) score = iid == 0 ? (known ? 1600 : 750) / (r.nerr + 1) : (known ? 1000 / (r.nerr + 1) : -1);
+      else          score = (known ? 1800 : 1400) / (r.nerr + 1);
+      const bool is_acc = (accepted >> lane) & 1;
+      const bool scored = reached && score >= 0;
+      st_oop   += __popcll (__ballot (reached && score > -2));
+      st_demod += __popcll (__ballot (scored));
+      st_bad   += __popcll (__ballot (scored && !is_acc));
+      st_unk   += __popcll (__ballot (scored && !is_acc));      // every reject past the score is "unknown ICAO" (-1)
+      const int ebits = (acq ? (masked ? r.nerr : 0) : ap ? 0 : (r.crc ? r.nerr : 0));
+      st_good  += __popcll (__ballot (is_acc && ebits == 0));
+      st_fix1  += __popcll (__ballot (is_acc && ebits == 1));
+      st_fix2  += __popcll (__ballot (is_acc && ebits == 2));
+      nacc += __popcll (accepted);
+      // write back: flags bit0 = accepted, pad[0..1] = score
+      if (have) {
+        const uint8_t nf = is_acc ? 1 : 0;
+        const int16_t sc16 = int16_t (score);
+        if (r.flags != nf || *reinterpret_cast<const int16_t *> (r.pad) != sc16) {
+          rp->flags = nf;
+          *reinterpret_cast<int16_t *> (rp->pad) = sc16;
+        }
+      }
+      // valid preambles hidden inside the skipped-over part of accepted messages
+      if (p.vp_bitmap) {
+        for (u64 am = accepted; am; am &= am - 1) {
+          const int a = __builtin_ctzll (am);
+          const uint32_t ja = rdlane (j, a);
+          const uint32_t lo = ja + 1, hi = min (rdlane (my_skip, a), blk_len);      // positions [lo, hi) never examined
+          if (lo >= hi) continue;
+          const uint64_t g0 = blk_pos0 + lo, g1 = blk_pos0 + hi;
+          const uint64_t wi = (g0 >> 6) + lane;
+          uint32_t c = 0;
+          if (wi <= ((g1 - 1) >> 6)) {
+            u64 bits = p.vp_bitmap[wi];
+            if (wi == (g0 >> 6)) bits &= ~0ull << (g0 & 63);
+            if (wi == ((g1 - 1) >> 6) && (g1 & 63)) bits &= (1ull << (g1 & 63)) - 1;
+            c = __popcll (bits);
+          }
+          if (c) atomicAdd (&w.counter[kStSkippedVp], c);
+        }
+      }
+    }
+    if (lane == 0 && p.acc_counts[strip] != nacc) p.acc_counts[strip] = nacc;
+    if (lane == 0) w.counter[kStAccepted] += nacc;
+  }
+  __builtin_amdgcn_s_waitcnt (0xc07f);
+  __builtin_amdgcn_wave_barrier ();
+
+  // delta of this block + change detection against the previous round
+  bool diff = false;
+  for (int i = lane; i < int (kIcaoSlots); i += 64) {
+    const bool wr = (w.written[i >> 5] >> (i & 31)) & 1;
+    const uint32_t nv = wr ? (kDeltaWritten | w.cache[i]) : 0u;
+    uint32_t *d = p.delta + size_t (blk) * kIcaoSlots + i;
+    if (*d != nv) { *d = nv; diff = true; }
+  }
+  if (__ballot (diff) && lane == 0) atomicOr (p.changed, 1u);
+  if (lane == 0) {
+    uint32_t *o = p.blk_stats + size_t (blk) * kBlkStats;
+    o[kStDemodulated] = st_demod; o[kStOutOfPhase] = st_oop; o[kStGood] = st_good; o[kStBad] = st_bad;
+    o[kStFix1] = st_fix1; o[kStFix2] = st_fix2; o[kStUnknown] = st_unk;
+    o[kStSkippedVp] = w.counter[kStSkippedVp]; o[kStAccepted] = w.counter[kStAccepted];
+  }
+}
+
+// ---- propagate the per-block cache writes down the block axis ----
+constexpr int kSnapChunk = 32;
+
+// last write per (chunk of blocks, slot)
+__global__ __launch_bounds__ (256)
+void snap_chunk_last_kernel (const uint32_t *delta, uint32_t nblocks, uint32_t *chunk_last)
+{
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x, chunk = blockIdx.y;
+  if (s >= kIcaoSlots) return;
+  uint32_t v = 0;
+  const uint32_t b0 = chunk * kSnapChunk, b1 = min (b0 + kSnapChunk, nblocks);
+  for (uint32_t b = b0; b < b1; b++) { const uint32_t d = delta[size_t (b) * kIcaoSlots + s]; if (d & kDeltaWritten) v = d; }
+  chunk_last[size_t (chunk) * kIcaoSlots + s] = v;
+}
+
+// serial over chunks, one thread per slot: cache at the entry of every chunk; also the cache after the last block
+__global__ __launch_bounds__ (256)
+void snap_chunk_scan_kernel (const uint32_t *chunk_last, uint32_t nchunks, const uint32_t *cache_in, uint32_t *chunk_entry,
+                             uint32_t *cache_out)
+{
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= kIcaoSlots) return;
+  uint32_t cur = cache_in[s];
+  for (uint32_t c = 0; c < nchunks; c++) {
+    chunk_entry[size_t (c) * kIcaoSlots + s] = cur;
+    const uint32_t d = chunk_last[size_t (c) * kIcaoSlots + s];
+    if (d & kDeltaWritten) cur = d & ~kDeltaWritten;
+  }
+  cache_out[s] = cur;
+}
+
+__global__ __launch_bounds__ (256)
+void snap_fill_kernel (const uint32_t *delta, uint32_t nblocks, const uint32_t *chunk_entry, uint32_t *snap_in)
+{
+  const uint32_t s = blockIdx.x * 256 + threadIdx.x, chunk = blockIdx.y;
+  if (s >= kIcaoSlots) return;
+  uint32_t cur = chunk_entry[size_t (chunk) * kIcaoSlots + s];
+  const uint32_t b0 = chunk * kSnapChunk, b1 = min (b0 + kSnapChunk, nblocks);
+  for (uint32_t b = b0; b < b1; b++) {
+    snap_in[size_t (b) * kIcaoSlots + s] = cur;
+    const uint32_t d = delta[size_t (b) * kIcaoSlots + s];
+    if (d & kDeltaWritten) cur = d & ~kDeltaWritten;
+  }
+}
+
+// snap_in[b][*] = cache_in for every block (first-round guess)
+__global__ __launch_bounds__ (256)
+void snap_broadcast_kernel (const uint32_t *cache_in, uint32_t nblocks, uint32_t *snap_in)
+{
+  const size_t i = size_t (blockIdx.x) * 256 + threadIdx.x;
+  if (i < size_t (nblocks) * kIcaoSlots) snap_in[i] = cache_in[i % kIcaoSlots];
+}
+
+// ---- emit: accepted records -> modes_message, in order, with the signal level ----
+struct MsgOut {            // mirrors modes_message (include/modes_hip.h), 56 bytes
+  uint64_t timestamp; uint8_t msg[14]; uint8_t msg_bits, msg_type; uint32_t addr, crc; int16_t score; uint8_t error_bits, phase;
+  uint32_t block; double sig_level; uint32_t j, reserved;
+};
+static_assert (sizeof (MsgOut) == 56, "modes_message layout");
+
+template <int CONV>
+__global__ __launch_bounds__ (256)
+void emit2400_kernel (const EmitParams p)
+{
+  const uint32_t strip = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (strip >= p.nstrips) return;
+  const uint32_t nacc = p.acc_counts[strip];
+  if (!nacc) return;
+  // offset of this strip in the output = chunk base + accepted counts of the earlier strips of the chunk
+  const uint32_t chunk = strip / kScanChunk, first = chunk * kScanChunk;
+  uint64_t before = 0;
+  for (uint32_t i = first + lane; i < strip; i += 64) before += p.acc_counts[i];
+  for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor (before, d, 64);
+  MsgOut *out = reinterpret_cast<MsgOut *> (p.messages) + p.chunk_sum[chunk] + before;
+  const Record *recs = p.records + size_t (strip) * p.cap;
+  uint32_t k = 0;
+  const uint32_t nrec = p.counts[strip];
+  for (uint32_t i = 0; k < nacc && i < nrec; i++) {
+    const Record r = recs[i];                     // same record for every lane
+    if (!(r.flags & 1)) continue;
+    const uint64_t P = uint64_t (strip) * kStrip + r.off;
+    const int mbits = msg_bits_for_df (r.df);
+    const int slen = mbits * 12 / 5;
+    u64 acc = 0;                                  // ref: src/demod-2400.c:486-497
+    for (int q = lane; q < slen; q += 64) {
+      const uint32_t m = CONV == kConvMagU16 ? 0u : mag_of_V<CONV> (p.iq, p.nsamples, p.halo, p.ov, p.block_samples, p.lut256, (long long) P + 19 + q);
+      acc += u64 (m * m);
+    }
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor (acc, d, 64);
+    if (lane == 0) {
+      MsgOut o;
+      memset (&o, 0, sizeof o);
+      const uint64_t blk = P / p.block_samples, j = P % p.block_samples;
+      const uint64_t counter = p.first_sample + blk * p.block_samples;
+      o.timestamp = uint64_t ((double (counter) * 12E6) / double (p.sample_rate)) + j * 5 + r.phase;   // ref: src/infile.c:143, src/demod-2400.c:467
+      for (int b = 0; b < 14; b++) o.msg[b] = r.msg[b];
+      const bool ap = r.cls == kClsAP || r.cls == kClsAP2, acq = r.cls == kClsDF11;
+      int eb = 0;
+      if (acq && (r.crc & 0xFFFF80u)) eb = r.nerr;
+      if (!ap && !acq && r.crc) eb = r.nerr;
+      if (eb >= 1) o.msg[r.bit0 >> 3] ^= uint8_t (0x80u >> (r.bit0 & 7));
+      if (eb >= 2) o.msg[r.bit1 >> 3] ^= uint8_t (0x80u >> (r.bit1 & 7));
+      const uint32_t aa = (uint32_t (o.msg[1]) << 16) | (uint32_t (o.msg[2]) << 8) | o.msg[3];
+      o.msg_bits = uint8_t (mbits);
+      o.msg_type = uint8_t (r.df >= 24 ? 24 : r.df);
+      o.addr = ap ? r.crc : acq ? aa : (aa | non_icao_flag_dev (o.msg, r.df));
+      o.crc = r.crc;
+      o.score = *reinterpret_cast<const int16_t *> (r.pad);
+      o.error_bits = uint8_t (eb);
+      o.phase = r.phase;
+      o.block = uint32_t (p.first_sample / p.block_samples + blk);
+      o.sig_level = (double (acc) / 65535.0 / 65535.0) / double (slen);
+      o.j = uint32_t (j);
+      out[k] = o;
+    }
+    k++;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers (called from engine.cpp)
 // ------------------------------------------------------------------------------------------
@@ -906,6 +1233,48 @@ hipError_t launch_convert_float (int conv, const uint8_t *iq, uint16_t *mag, siz
   }
 #undef FLOATCONV
   if (power_out) hipLaunchKernelGGL (power_seq_kernel, dim3 (1), dim3 (64), 0, stream, mag_sq, n, power_out);
+  return hipGetLastError ();
+}
+
+hipError_t launch_accept2400 (const AcceptParams &p, hipStream_t stream)
+{
+  if (p.nblocks == 0) return hipSuccess;
+  hipLaunchKernelGGL (accept2400_kernel, dim3 ((p.nblocks + 3) / 4), dim3 (256), 0, stream, p);
+  return hipGetLastError ();
+}
+
+// delta -> snap_in for the next round; chunk_last/chunk_entry hold (nblocks/32 + 1) * 1024 words each
+hipError_t launch_snapshots (const uint32_t *delta, uint32_t nblocks, const uint32_t *cache_in, uint32_t *chunk_last,
+                             uint32_t *chunk_entry, uint32_t *snap_in, uint32_t *cache_out, hipStream_t stream)
+{
+  if (nblocks == 0) return hipSuccess;
+  const uint32_t nchunks = (nblocks + kSnapChunk - 1) / kSnapChunk;
+  hipLaunchKernelGGL (snap_chunk_last_kernel, dim3 (kIcaoSlots / 256, nchunks), dim3 (256), 0, stream, delta, nblocks, chunk_last);
+  hipLaunchKernelGGL (snap_chunk_scan_kernel, dim3 (kIcaoSlots / 256), dim3 (256), 0, stream, chunk_last, nchunks, cache_in, chunk_entry, cache_out);
+  hipLaunchKernelGGL (snap_fill_kernel, dim3 (kIcaoSlots / 256, nchunks), dim3 (256), 0, stream, delta, nblocks, chunk_entry, snap_in);
+  return hipGetLastError ();
+}
+
+hipError_t launch_snap_broadcast (const uint32_t *cache_in, uint32_t nblocks, uint32_t *snap_in, hipStream_t stream)
+{
+  if (nblocks == 0) return hipSuccess;
+  const size_t n = size_t (nblocks) * kIcaoSlots;
+  hipLaunchKernelGGL (snap_broadcast_kernel, dim3 ((unsigned) ((n + 255) / 256)), dim3 (256), 0, stream, cache_in, nblocks, snap_in);
+  return hipGetLastError ();
+}
+
+hipError_t launch_emit2400 (const EmitParams &p, hipStream_t stream)
+{
+  if (p.nstrips == 0) return hipSuccess;
+  const dim3 grid ((p.nstrips + 3) / 4), block (256);
+  switch (p.conv) {
+    case kConvUc8Lut: case kConvUc8LutPower: hipLaunchKernelGGL (emit2400_kernel<kConvUc8Lut>, grid, block, 0, stream, p); break;
+    case kConvUc8Generic:     hipLaunchKernelGGL (emit2400_kernel<kConvUc8Generic>, grid, block, 0, stream, p); break;
+    case kConvSc16Int:        hipLaunchKernelGGL (emit2400_kernel<kConvSc16Int>, grid, block, 0, stream, p); break;
+    case kConvSc16Generic:    hipLaunchKernelGGL (emit2400_kernel<kConvSc16Generic>, grid, block, 0, stream, p); break;
+    case kConvSc16Q11Generic: hipLaunchKernelGGL (emit2400_kernel<kConvSc16Q11Generic>, grid, block, 0, stream, p); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError ();
 }
 

@@ -13,9 +13,20 @@ FMT = {"uc8": da.INPUT_UC8, "sc16": da.INPUT_SC16, "sc16q11": da.INPUT_SC16Q11}
 
 
 def engine_run(iq, fmt, **kw):
+    """Runs the engine twice -- ordered accept pass on the device (default) and on the host -- and checks
+    that both give the same messages and statistics before handing them to the oracle comparison."""
     e = da.Engine(2400000, FMT[fmt], **kw)
     e.run_host(iq)
-    return e.messages(), e.stats()
+    got, st = e.messages(), e.stats()
+    h = da.Engine(2400000, FMT[fmt], host_replay=True, **kw)
+    h.run_host(iq)
+    got_h, st_h = h.messages(), h.stats()
+    assert got.tobytes() == got_h.tobytes()
+    for k in st:
+        if k != "replay_rounds":
+            assert st[k] == st_h[k], k
+    assert np.array_equal(e.get_icao(), h.get_icao())
+    return got, st
 
 
 @pytest.mark.parametrize("fix_bits", [0, 1, 2])
