@@ -25,12 +25,28 @@ constexpr int kQ2Cap = 256;           // stage-C survivors per strip
 constexpr int kLook2400 = 320;     // samples a position may look ahead (<= 290 needed; ref: src/demod-2400.c:339-412,488-494)
 constexpr int kTilePad = 16;       // slack so global loads can start 16-sample aligned
 
+// ---- scan kernel geometry (2.0 MS/s) -------------------------------------------------
+constexpr int kLook2000 = 256;        // samples a position may look ahead (16 + 224 payload, Mode A ~75; ref: src/demod-2000.c:757,768)
+constexpr int kBack2000 = 16;         // tile slack in front: pre[-1] of the phase correction + 16-sample load alignment
+constexpr int kTile2000 = kStrip + kLook2000 + kBack2000 + 16;
+constexpr int kPlaneWords2000 = (kStrip + kLook2000) / 64;   // 36 words of GT/LT bits
+constexpr int kCap2000 = 64;          // records per strip: every valid preamble leaves one
+constexpr int kQ2Cap2000 = 256;
+
+// Record.phase carries these for the 2.0 MS/s path
+constexpr uint8_t kInfoDemodMask = 3;     // Modes.stat.demodulated increments of the slice (0..2)
+constexpr uint8_t kInfoDecode = 4;        // reached decode_mode_S_message (msg_len, SNR, errors <= 3; ref: src/demod-2000.c:954)
+constexpr uint8_t kInfoStaticReject = 8;  // ... which fails whatever the ICAO cache holds (rc -2 / -3)
+constexpr uint8_t kInfoStale = 16;        // message bytes the slicer never wrote would be read
+constexpr uint8_t kInfoOutOfPhase = 32;   // detect_out_of_phase() != 0 at this preamble
+
 // Candidate classes (what the ordered accept pass needs to know about a record)
 enum Cls : uint8_t {
   kClsAP = 0,      // DF0/4/5/16/24: address = CRC, score 1000 / -1      (ref: src/dump1090.c:3302-3307)
   kClsAP2 = 1,     // DF20/21:       address = CRC, score 1000 / -2      (ref: src/dump1090.c:3355-3359)
   kClsDF11 = 2,    // table hit on syndrome & 0xFFFF80, <= 1 error       (ref: src/dump1090.c:3309-3338)
-  kClsES = 3       // DF17/18 with a table hit                           (ref: src/dump1090.c:3340-3353)
+  kClsES = 3,      // DF17/18 with a table hit                           (ref: src/dump1090.c:3340-3353)
+  kClsModeA = 4    // Mode A/C reply: always emitted                     (ref: src/demod-2000.c:677-701)
 };
 
 // One candidate that survived every state-independent rejection.  32 bytes.
@@ -73,6 +89,10 @@ struct ScanParams {
   int32_t         write_records;   // 0 = timing variant that keeps everything but the final store
   int32_t         debug_stop;      // profiling aid: 1..3 = leave after stage A/B/C (results are then meaningless)
   uint64_t       *vp_bitmap;       // [nstrips][64]: bit = position reached scoring (Modes.stat.valid_preamble), or nullptr
+  // 2.0 MS/s path
+  const uint16_t *log10_lut;       // 65536 entries (ref: src/dump1090.c:410-423)
+  const uint32_t *crc_table;       // 256 entries (ref: src/crc.c:43-54)
+  int32_t         mode_ac;
 };
 
 }  // namespace modes
@@ -82,7 +102,7 @@ namespace modes {
 // ---- ordered accept pass on the device ------------------------------------------------------
 constexpr uint32_t kDeltaWritten = 0x80000000u;   // marks an ICAO slot a block wrote (addresses use 25 bits)
 
-enum BlkStat : int { kStDemodulated = 0, kStOutOfPhase, kStGood, kStBad, kStFix1, kStFix2, kStUnknown, kStSkippedVp, kStAccepted, kBlkStats = 12 };
+enum BlkStat : int { kStDemodulated = 0, kStOutOfPhase, kStGood, kStBad, kStFix1, kStFix2, kStUnknown, kStSkippedVp, kStAccepted, kStVp, kStModeAC, kBlkStats = 12 };
 
 struct AcceptParams {
   Record         *records;       // [nstrips][cap]; flags/score are written back
@@ -96,6 +116,7 @@ struct AcceptParams {
   uint32_t       *blk_stats;     // [nblocks][kBlkStats]
   const uint64_t *vp_bitmap;     // may be null
   uint32_t       *changed;       // set to 1 when a delta entry differs from the previous round
+  int32_t         mode;          // 2400 or 2000: which demodulator's loop is replayed
 };
 
 struct EmitParams {
@@ -106,6 +127,7 @@ struct EmitParams {
   const uint16_t *lut256;
   uint64_t        first_sample; uint32_t sample_rate;
   void           *messages;      // modes_message[total]
+  int32_t         mode;          // 2400 or 2000
 };
 
 }  // namespace modes

@@ -1,0 +1,268 @@
+// Device-side helpers shared by the gfx950 kernels of libmodes_hip.so: sample converters,
+// wave/DPP primitives and the staging of a strip of magnitudes into a wave-private LDS tile.
+// "ref:" citations are relative to the reference's root.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "common.h"
+
+namespace modes {
+static __constant__ uint32_t c_single_bit[kLongBits];     // ref: src/crc.c:35,56-61
+static __constant__ float    c_uc8_float[256];            // (float)((b-127.5)/127.5), ref: src/convert.c:132
+
+// Every translation unit that includes this header owns a copy of the two tables; its launcher file
+// exposes one upload call built on this.
+static inline hipError_t upload_constants_tu (const uint32_t *single_bit, const float *uc8_float)
+{
+  hipError_t e = hipMemcpyToSymbol (HIP_SYMBOL (c_single_bit), single_bit, sizeof (uint32_t) * kLongBits);
+  if (e != hipSuccess) return e;
+  return hipMemcpyToSymbol (HIP_SYMBOL (c_uc8_float), uc8_float, sizeof (float) * 256);
+}
+
+using u64 = unsigned long long;
+
+// ------------------------------------------------------------------------------------------
+// converters, one sample
+// ------------------------------------------------------------------------------------------
+
+// ref: src/convert.c:254-292
+__device__ __forceinline__ uint16_t mag_sc16_int (int i16, int q16)
+{
+  uint32_t I = uint32_t (i16 < 0 ? -i16 : i16), Q = uint32_t (q16 < 0 ? -q16 : q16), mag;
+  if (I < Q) mag = (I < ((106u * Q) >> 8)) ? (12868u * I + 64692u * Q) >> 16 : (36646u * I + 54842u * Q) >> 16;
+  else       mag = (I < ((618u * Q) >> 8)) ? (54842u * I + 36646u * Q) >> 16 : (64692u * I + 12868u * Q) >> 16;
+  return uint16_t (mag);
+}
+
+// ref: src/convert.c:142-147 -- the tail shared by the three float converters, DC block already applied
+__device__ __forceinline__ uint16_t mag_from_float (float fI, float fQ, float *mag_sq_out)
+{
+  float mag_sq = __fadd_rn (__fmul_rn (fI, fI), __fmul_rn (fQ, fQ));
+  if (mag_sq > 1.0f) mag_sq = 1.0f;
+  if (mag_sq_out) *mag_sq_out = mag_sq;
+  const double v = __dadd_rn (__dmul_rn (double (sqrtf (mag_sq)), 65535.0), 0.5);
+  return uint16_t (int (v));
+}
+
+// ------------------------------------------------------------------------------------------
+// wave helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id () { return int (__builtin_amdgcn_mbcnt_hi (~0u, __builtin_amdgcn_mbcnt_lo (~0u, 0u))); }
+
+
+// ---- DPP cross-lane helpers (GFX9 row/wave controls; no LDS round trip) ----
+template <int CTRL, int ROW_MASK = 0xF, bool BOUND = true>
+__device__ __forceinline__ uint32_t dpp_mov (uint32_t v)
+{
+  return uint32_t (__builtin_amdgcn_update_dpp (0, int (v), CTRL, ROW_MASK, 0xF, BOUND));
+}
+// every lane of a 16-lane row receives the XOR / OR of the row (row_ror:1,2,4,8)
+__device__ __forceinline__ uint32_t row_xor (uint32_t v)
+{
+  v ^= dpp_mov<0x121> (v); v ^= dpp_mov<0x122> (v); v ^= dpp_mov<0x124> (v); v ^= dpp_mov<0x128> (v);
+  return v;
+}
+__device__ __forceinline__ uint32_t row_or (uint32_t v)
+{
+  v |= dpp_mov<0x121> (v); v |= dpp_mov<0x122> (v); v |= dpp_mov<0x124> (v); v |= dpp_mov<0x128> (v);
+  return v;
+}
+
+// inclusive +scan over the 64 lanes: row_shr 1,2,4,8 inside each row, then row_bcast:15 / row_bcast:31
+__device__ __forceinline__ int wave_incl_scan (int v, int lane)
+{
+  (void) lane;
+  uint32_t u = uint32_t (v);
+  u += dpp_mov<0x111> (u); u += dpp_mov<0x112> (u); u += dpp_mov<0x114> (u); u += dpp_mov<0x118> (u);
+  u += dpp_mov<0x142, 0xA, false> (u);
+  u += dpp_mov<0x143, 0xC, false> (u);
+  return int (u);
+}
+
+__device__ __forceinline__ uint32_t wave_xor (uint32_t v)
+{
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v ^= uint32_t (__shfl_xor (int (v), d, 64));
+  return v;
+}
+
+__device__ __forceinline__ u64 funnel (u64 w, u64 nx, int k) { return (w >> k) | (nx << (64 - k)); }
+
+// per-byte bit reversal of a 32-bit word (message bit k sits at mask bit k, MSB-first bytes wanted)
+__device__ __forceinline__ uint32_t rev_in_bytes (uint32_t x) { return __builtin_bswap32 (__brev (x)); }
+
+// ------------------------------------------------------------------------------------------
+// 2.4 MS/s slicers.  A data bit that starts `f` fifths of a sample after m[0] is sliced at
+// sample f/5 with the weights of row f%5 (ref: src/demod-2400.c:32-55, 339-412).
+// ------------------------------------------------------------------------------------------
+template <int F>
+__device__ __forceinline__ int slice_const (const int *s)   // s[] = samples as ints, compile-time position
+{
+  constexpr int i = F / 5, r = F % 5;
+  if (r == 0) return 5 * s[i] - 3 * s[i + 1] - 2 * s[i + 2];
+  if (r == 1) return 4 * s[i] - s[i + 1] - 3 * s[i + 2];
+  if (r == 2) return 3 * s[i] + s[i + 1] - 4 * s[i + 2];
+  if (r == 3) return 2 * s[i] + 3 * s[i + 1] - 5 * s[i + 2];
+  return s[i] + 5 * s[i + 1] - 5 * s[i + 2] - s[i + 3];
+}
+template <int R> __device__ __forceinline__ constexpr int corr_weight () { return R == 0 ? 26 : R == 1 ? 38 : R == 2 ? 38 : R == 3 ? 26 : 19; }
+
+// correlate_check for start phase T over the first five bits (ref: src/demod-2400.c:86-129);
+// also returns those five sliced bits (bit 4 = first data bit).
+template <int T>
+__device__ __forceinline__ int check_phase (const int *s, int *five_bits)
+{
+  const int a = slice_const<T> (s), b = slice_const<T + 12> (s), c = slice_const<T + 24> (s),
+            d = slice_const<T + 36> (s), e = slice_const<T + 48> (s);
+  *five_bits = ((a > 0) << 4) | ((b > 0) << 3) | ((c > 0) << 2) | ((d > 0) << 1) | (e > 0);
+  return abs (a * corr_weight<T % 5> ()) + abs (b * corr_weight<(T + 12) % 5> ()) + abs (c * corr_weight<(T + 24) % 5> ()) +
+         abs (d * corr_weight<(T + 36) % 5> ()) + abs (e * corr_weight<(T + 48) % 5> ());
+}
+
+// bytes sliced for a DF (ref: src/demod-2400.c:416-435): 7, 14 or 0 (= give up after byte 0)
+__device__ __forceinline__ int slice_bytes_for_df (int df)
+{
+  const uint32_t short_set = (1u << 0) | (1u << 4) | (1u << 5) | (1u << 11);
+  const uint32_t long_set = (1u << 16) | (1u << 17) | (1u << 18) | (1u << 20) | (1u << 21) | (1u << 24);
+  return ((short_set >> df) & 1) ? kShortBytes : ((long_set >> df) & 1) ? kLongBytes : 0;
+}
+// ref: src/dump1090.c:1427-1432
+__device__ __forceinline__ int msg_bits_for_df (int df)
+{
+  return (df == 16 || df == 17 || df == 19 || df == 20 || df == 21) ? kLongBits : kShortBits;
+}
+
+// Wave-cooperative search of a sorted error table (n <= 4096): two probes per lane.
+__device__ __forceinline__ int table_find (const ErrEntry *tab, int n, uint32_t syn, int lane)
+{
+  if (n <= 0) return -1;
+  const int step = (n + 63) >> 6;
+  const int first = lane * step;
+  const bool le = first < n && tab[first].syndrome <= syn;
+  const u64 m = __ballot (le);
+  if (!m) return -1;
+  const int seg = 63 - __builtin_clzll (m);       // `le` is monotone in the lane index
+  const int idx = seg * step + lane;
+  const bool eq = lane < step && idx < n && tab[idx].syndrome == syn;
+  const u64 h = __ballot (eq);
+  return h ? seg * step + int (__builtin_ctzll (h)) : -1;
+}
+
+// ------------------------------------------------------------------------------------------
+// staging: convert samples [a_lo, a_lo + count) into w.tile[0 .. count)
+// ------------------------------------------------------------------------------------------
+template <int CONV> struct RawWords { static constexpr int n = (CONV == kConvUc8Lut || CONV == kConvUc8LutPower) ? 2 : (CONV == kConvUc8Generic || CONV == kConvMagU16) ? 4 : 8; };
+
+// raw IQ of 8 consecutive samples starting at n0 (a multiple of 8, whole chunk inside the shard)
+template <int CONV>
+__device__ __forceinline__ void load_raw8 (const ScanParams &p, long long n0, uint32_t *d)
+{
+  if (CONV == kConvUc8Lut || CONV == kConvUc8LutPower) {
+    // as written: output sample i of a block reads input BYTE i of that block (ref: src/convert.c:19,29)
+    const uint64_t blk = uint64_t (n0) / p.block_samples, i = uint64_t (n0) % p.block_samples;
+    const uint2 v = *reinterpret_cast<const uint2 *> (p.iq + blk * 2 * p.block_samples + i);
+    d[0] = v.x; d[1] = v.y;
+  } else if (CONV == kConvUc8Generic || CONV == kConvMagU16) {
+    const uint4 v = *reinterpret_cast<const uint4 *> (p.iq + 2 * n0);
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  } else {
+    const uint4 *src = reinterpret_cast<const uint4 *> (p.iq + 4 * n0);
+    const uint4 v0 = src[0], v1 = src[1];
+    d[0] = v0.x; d[1] = v0.y; d[2] = v0.z; d[3] = v0.w; d[4] = v1.x; d[5] = v1.y; d[6] = v1.z; d[7] = v1.w;
+  }
+}
+
+template <int CONV>
+__device__ __forceinline__ uint4 convert_raw8 (const uint16_t *lut, const uint32_t *d)
+{
+  if (CONV == kConvMagU16) { uint4 pk; pk.x = d[0]; pk.y = d[1]; pk.z = d[2]; pk.w = d[3]; return pk; }
+  uint16_t out[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (CONV == kConvUc8Lut || CONV == kConvUc8LutPower)
+      out[k] = lut[(d[k >> 2] >> (8 * (k & 3))) & 0xFF];
+    else if (CONV == kConvUc8Generic) {
+      const uint32_t iqp = d[k >> 1] >> (16 * (k & 1));
+      out[k] = mag_from_float (c_uc8_float[iqp & 0xFF], c_uc8_float[(iqp >> 8) & 0xFF], nullptr);
+    } else {
+      const int I = int (int16_t (d[k] & 0xFFFF)), Q = int (int16_t (d[k] >> 16));
+      if (CONV == kConvSc16Int) out[k] = mag_sc16_int (I, Q);
+      else {
+        const float sc = CONV == kConvSc16Generic ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
+        out[k] = mag_from_float (float (I) * sc, float (Q) * sc, nullptr);
+      }
+    }
+  }
+  uint4 pk;
+  pk.x = out[0] | (uint32_t (out[1]) << 16); pk.y = out[2] | (uint32_t (out[3]) << 16);
+  pk.z = out[4] | (uint32_t (out[5]) << 16); pk.w = out[6] | (uint32_t (out[7]) << 16);
+  return pk;
+}
+
+
+// kTileCount (a multiple of 8) samples starting at sample index a_lo (a multiple of 8; may be negative or run
+// past the end: those read the halo / zeros).  `lut` = the as-written uc8 table in LDS.
+template <int CONV, int kTileCount>
+__device__ __forceinline__ void stage_tile (uint16_t *tile, const uint16_t *lut, const ScanParams &p, long long a_lo, int lane)
+{
+  constexpr int kTileChunks = kTileCount / 8;
+  constexpr int kTileIters = (kTileChunks + 63) / 64;
+  const long long N = (long long) (CONV == kConvMagU16 ? p.navail : p.nsamples);
+  constexpr int NW = RawWords<CONV>::n;
+  if (a_lo >= 0 && a_lo + kTileCount <= N) {
+    // interior strip: every load is issued before the first conversion
+    uint32_t raw[kTileIters][NW];
+#pragma unroll
+    for (int it = 0; it < kTileIters; it++) {
+      const int ch = it * 64 + lane;
+      if (ch < kTileChunks) load_raw8<CONV> (p, a_lo + 8 * ch, raw[it]);
+    }
+#pragma unroll
+    for (int it = 0; it < kTileIters; it++) {
+      const int ch = it * 64 + lane;
+      if (ch < kTileChunks) *reinterpret_cast<uint4 *> (&tile[8 * ch]) = convert_raw8<CONV> (lut, raw[it]);
+    }
+    return;
+  }
+  // first / last strips of the shard: per-sample bounds
+  for (int c = lane * 8; c < kTileCount; c += 64 * 8) {
+    const long long n0 = a_lo + c;
+    uint4 pk;
+    if (n0 >= 0 && n0 + 8 <= N) {
+      uint32_t d[NW];
+      load_raw8<CONV> (p, n0, d);
+      pk = convert_raw8<CONV> (lut, d);
+    } else {
+      uint16_t out[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const long long n = n0 + k;
+        uint16_t m = 0;
+        if (n < 0) {
+          if (p.halo && n + (long long) p.ov >= 0) m = p.halo[n + (long long) p.ov];
+        } else if (n < N) {
+          if (CONV == kConvMagU16) m = reinterpret_cast<const uint16_t *> (p.iq)[n];
+          else if (CONV == kConvUc8Lut || CONV == kConvUc8LutPower) {
+            const uint64_t blk = uint64_t (n) / p.block_samples, i = uint64_t (n) % p.block_samples;
+            m = lut[p.iq[blk * 2 * p.block_samples + i]];
+          } else if (CONV == kConvUc8Generic) {
+            m = mag_from_float (c_uc8_float[p.iq[2 * n]], c_uc8_float[p.iq[2 * n + 1]], nullptr);
+          } else {
+            const int16_t *s = reinterpret_cast<const int16_t *> (p.iq) + 2 * n;
+            if (CONV == kConvSc16Int) m = mag_sc16_int (s[0], s[1]);
+            else {
+              const float sc = CONV == kConvSc16Generic ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
+              m = mag_from_float (float (s[0]) * sc, float (s[1]) * sc, nullptr);
+            }
+          }
+        }
+        out[k] = m;
+      }
+      pk.x = out[0] | (uint32_t (out[1]) << 16); pk.y = out[2] | (uint32_t (out[3]) << 16);
+      pk.z = out[4] | (uint32_t (out[5]) << 16); pk.w = out[6] | (uint32_t (out[7]) << 16);
+    }
+    *reinterpret_cast<uint4 *> (&tile[c]) = pk;
+  }
+}
+
+}  // namespace modes

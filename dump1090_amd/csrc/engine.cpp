@@ -69,6 +69,8 @@ struct DeviceTables {
   int short_n = 0, long_n = 0;
   uint16_t *lut256 = nullptr;
   uint32_t *bloom_short = nullptr, *bloom_long = nullptr;
+  uint16_t *log10_lut = nullptr;
+  uint32_t *crc_table = nullptr;
 };
 
 template <typename T>
@@ -116,6 +118,7 @@ int select_converter (int fmt, bool dc, bool power)
 struct modes_engine {
   modes_engine_config cfg;
   int conv = -1;
+  int mode = 2400;                          // which demodulator: 2000 / 2400
   uint32_t ov = 0, block_samples = 0;
   CrcTables crc;
   DeviceTables tabs;
@@ -164,6 +167,14 @@ int setup_tables (modes_engine *e)
     else                    { t.long_tab = p;  t.long_n = int (d.size ()); t.bloom_long = pb; }
   }
   HIP_TRY (hipMalloc (reinterpret_cast<void **> (&e->d_stats), 8 * sizeof (unsigned long long)));
+  if (e->cfg.sample_rate == 2000000) {
+    std::vector<uint16_t> l10 (65536);
+    build_log10_lut (l10.data ());
+    HIP_TRY (hipMalloc (reinterpret_cast<void **> (&t.log10_lut), l10.size () * sizeof (uint16_t)));
+    HIP_TRY (hipMemcpy (t.log10_lut, l10.data (), l10.size () * sizeof (uint16_t), hipMemcpyHostToDevice));
+  }
+  HIP_TRY (hipMalloc (reinterpret_cast<void **> (&t.crc_table), 256 * sizeof (uint32_t)));
+  HIP_TRY (hipMemcpy (t.crc_table, e->crc.byte_table (), 256 * sizeof (uint32_t), hipMemcpyHostToDevice));
   return MODES_OK;
 }
 
@@ -198,6 +209,9 @@ int fill_scan_params (modes_engine *e, const void *d_iq, size_t nbytes, const ui
   sp->write_records = 1;
   sp->vp_bitmap = e->vp_bitmap.p;
   sp->debug_stop = 0;
+  sp->log10_lut = e->tabs.log10_lut;
+  sp->crc_table = e->tabs.crc_table;
+  sp->mode_ac = e->cfg.mode_ac;
   return MODES_OK;
 }
 
@@ -228,7 +242,8 @@ int run_accept_on_device (modes_engine *e, const ScanParams &sp, uint64_t first_
   ap.records = e->records.p; ap.counts = e->counts.p; ap.cap = e->cap; ap.nstrips = sp.nstrips;
   ap.strips_per_block = B / kStrip; ap.nblocks = nblocks; ap.nsamples = sp.nsamples; ap.block_samples = B;
   ap.snap_in = e->snap_in.p; ap.delta = e->delta.p; ap.acc_counts = e->acc_counts.p; ap.blk_stats = e->blk_stats.p;
-  ap.vp_bitmap = e->vp_bitmap.p; ap.changed = d_changed;
+  ap.vp_bitmap = e->mode == 2400 ? e->vp_bitmap.p : nullptr; ap.changed = d_changed;
+  ap.mode = e->mode;
 
   uint32_t rounds = 0;
   for (;;) {
@@ -261,7 +276,8 @@ int run_accept_on_device (modes_engine *e, const ScanParams &sp, uint64_t first_
   e->stats.CRC_single_bit_fix = sum[kStFix1]; e->stats.CRC_two_bits_fix = sum[kStFix2];
   e->stats.CRC_fixed = sum[kStFix1] + sum[kStFix2];
   e->stats.demod_rejected_unknown = sum[kStUnknown];
-  e->stats.valid_preamble -= sum[kStSkippedVp];
+  if (e->mode == 2000) e->stats.valid_preamble = sum[kStVp];      // every valid preamble is a record there
+  else e->stats.valid_preamble -= sum[kStSkippedVp];
   if (sum[kStAccepted] != nm) return fail (MODES_E_HIP, "accepted-count mismatch (%llu vs %zu)", (unsigned long long) sum[kStAccepted], nm);
 
   e->messages.resize (nm);
@@ -275,6 +291,7 @@ int run_accept_on_device (modes_engine *e, const ScanParams &sp, uint64_t first_
     ep.block_samples = sp.block_samples; ep.conv = sp.conv; ep.lut256 = sp.lut256;
     ep.first_sample = first_sample; ep.sample_rate = e->cfg.sample_rate;
     ep.messages = e->d_messages.p;
+    ep.mode = e->mode;
     HIP_TRY (launch_emit2400 (ep, stream));
     HIP_TRY (hipMemcpyAsync (e->messages.data (), e->d_messages.p, nm * sizeof (modes_message), hipMemcpyDeviceToHost, stream));
     HIP_TRY (hipStreamSynchronize (stream));
@@ -292,8 +309,10 @@ int modes_engine_create (const modes_engine_config *cfg, modes_engine **out)
 {
   if (!cfg || !out) return fail (MODES_E_ARG, "null argument");
   *out = nullptr;
-  if (cfg->sample_rate != 2400000)
-    return fail (MODES_E_ARG, "sample rate %u: only the 2.4 MS/s path is built so far", cfg->sample_rate);
+  if (cfg->sample_rate != 2400000 && cfg->sample_rate != 2000000)
+    return fail (MODES_E_ARG, "sample rate %u: the 2.0 and 2.4 MS/s paths are built so far", cfg->sample_rate);
+  if (cfg->sample_rate == 2000000 && (cfg->phase_enhance || cfg->mode_ac || cfg->host_replay))
+    return fail (MODES_E_ARG, "2.0 MS/s: phase_enhance / mode_ac / host_replay are not built yet");
   const int conv = select_converter (cfg->input_format, cfg->filter_dc != 0, cfg->compute_power != 0);
   if (conv < 0) return fail (MODES_E_ARG, "no suitable converter for format=%d power=%d DC=%d", cfg->input_format,
                              cfg->compute_power, cfg->filter_dc);
@@ -308,7 +327,8 @@ int modes_engine_create (const modes_engine_config *cfg, modes_engine **out)
   e->conv = conv;
   e->ov = trailing_samples (cfg->sample_rate);
   e->block_samples = kAsyncBufSize / bytes_per_sample (cfg->input_format);
-  e->cap = cfg->phase_enhance ? 128 : 32;
+  e->mode = cfg->sample_rate == 2000000 ? 2000 : 2400;
+  e->cap = e->mode == 2000 ? uint32_t (kCap2000) : cfg->phase_enhance ? 128 : 32;
   memset (&e->stats, 0, sizeof e->stats);
   int rc = setup_tables (e);
   if (rc != MODES_OK) { modes_engine_destroy (e); return rc; }
@@ -331,6 +351,8 @@ void modes_engine_destroy (modes_engine *e)
   if (e->tabs.lut256) (void) hipFree (e->tabs.lut256);
   if (e->tabs.bloom_short) (void) hipFree (e->tabs.bloom_short);
   if (e->tabs.bloom_long) (void) hipFree (e->tabs.bloom_long);
+  if (e->tabs.log10_lut) (void) hipFree (e->tabs.log10_lut);
+  if (e->tabs.crc_table) (void) hipFree (e->tabs.crc_table);
   if (e->d_stats) (void) hipFree (e->d_stats);
   delete e;
 }
@@ -364,7 +386,7 @@ int modes_engine_run_device (modes_engine *e, const void *d_iq, size_t nbytes, u
   if (rc != MODES_OK) return rc;
   if (sp.nstrips == 0) return MODES_OK;
 
-  HIP_TRY (launch_scan2400 (sp, stream));
+  HIP_TRY (e->mode == 2000 ? launch_scan2000 (sp, stream) : launch_scan2400 (sp, stream));
 
   // totals, then compact the per-strip slots into one ordered list
   const uint32_t nchunks = (sp.nstrips + 1023) / 1024;
@@ -459,7 +481,7 @@ int modes_engine_time_scan (modes_engine *e, const void *d_iq, size_t nbytes, in
   HIP_TRY (hipEventCreate (&a));
   HIP_TRY (hipEventCreate (&b));
   HIP_TRY (hipEventRecord (a, stream));
-  for (int i = 0; i < reps; i++) HIP_TRY (launch_scan2400 (sp, stream));
+  for (int i = 0; i < reps; i++) HIP_TRY (e->mode == 2000 ? launch_scan2000 (sp, stream) : launch_scan2400 (sp, stream));
   HIP_TRY (hipEventRecord (b, stream));
   HIP_TRY (hipEventSynchronize (b));
   float ms = 0;

@@ -10,140 +10,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "common.h"
+#include "device_common.h"
+#include "kernels.h"
 
 namespace modes {
 
-__constant__ uint32_t c_single_bit[kLongBits];     // ref: src/crc.c:35,56-61
-__constant__ float    c_uc8_float[256];            // (float)((b-127.5)/127.5), ref: src/convert.c:132
 
-using u64 = unsigned long long;
-
-// ------------------------------------------------------------------------------------------
-// converters, one sample
-// ------------------------------------------------------------------------------------------
-
-// ref: src/convert.c:254-292
-__device__ __forceinline__ uint16_t mag_sc16_int (int i16, int q16)
-{
-  uint32_t I = uint32_t (i16 < 0 ? -i16 : i16), Q = uint32_t (q16 < 0 ? -q16 : q16), mag;
-  if (I < Q) mag = (I < ((106u * Q) >> 8)) ? (12868u * I + 64692u * Q) >> 16 : (36646u * I + 54842u * Q) >> 16;
-  else       mag = (I < ((618u * Q) >> 8)) ? (54842u * I + 36646u * Q) >> 16 : (64692u * I + 12868u * Q) >> 16;
-  return uint16_t (mag);
-}
-
-// ref: src/convert.c:142-147 -- the tail shared by the three float converters, DC block already applied
-__device__ __forceinline__ uint16_t mag_from_float (float fI, float fQ, float *mag_sq_out)
-{
-  float mag_sq = __fadd_rn (__fmul_rn (fI, fI), __fmul_rn (fQ, fQ));
-  if (mag_sq > 1.0f) mag_sq = 1.0f;
-  if (mag_sq_out) *mag_sq_out = mag_sq;
-  const double v = __dadd_rn (__dmul_rn (double (sqrtf (mag_sq)), 65535.0), 0.5);
-  return uint16_t (int (v));
-}
-
-// ------------------------------------------------------------------------------------------
-// wave helpers
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lane_id () { return int (__builtin_amdgcn_mbcnt_hi (~0u, __builtin_amdgcn_mbcnt_lo (~0u, 0u))); }
-
-
-// ---- DPP cross-lane helpers (GFX9 row/wave controls; no LDS round trip) ----
-template <int CTRL, int ROW_MASK = 0xF, bool BOUND = true>
-__device__ __forceinline__ uint32_t dpp_mov (uint32_t v)
-{
-  return uint32_t (__builtin_amdgcn_update_dpp (0, int (v), CTRL, ROW_MASK, 0xF, BOUND));
-}
-// every lane of a 16-lane row receives the XOR / OR of the row (row_ror:1,2,4,8)
-__device__ __forceinline__ uint32_t row_xor (uint32_t v)
-{
-  v ^= dpp_mov<0x121> (v); v ^= dpp_mov<0x122> (v); v ^= dpp_mov<0x124> (v); v ^= dpp_mov<0x128> (v);
-  return v;
-}
-__device__ __forceinline__ uint32_t row_or (uint32_t v)
-{
-  v |= dpp_mov<0x121> (v); v |= dpp_mov<0x122> (v); v |= dpp_mov<0x124> (v); v |= dpp_mov<0x128> (v);
-  return v;
-}
-
-// inclusive +scan over the 64 lanes: row_shr 1,2,4,8 inside each row, then row_bcast:15 / row_bcast:31
-__device__ __forceinline__ int wave_incl_scan (int v, int lane)
-{
-  (void) lane;
-  uint32_t u = uint32_t (v);
-  u += dpp_mov<0x111> (u); u += dpp_mov<0x112> (u); u += dpp_mov<0x114> (u); u += dpp_mov<0x118> (u);
-  u += dpp_mov<0x142, 0xA, false> (u);
-  u += dpp_mov<0x143, 0xC, false> (u);
-  return int (u);
-}
-
-__device__ __forceinline__ uint32_t wave_xor (uint32_t v)
-{
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v ^= uint32_t (__shfl_xor (int (v), d, 64));
-  return v;
-}
-
-__device__ __forceinline__ u64 funnel (u64 w, u64 nx, int k) { return (w >> k) | (nx << (64 - k)); }
-
-// per-byte bit reversal of a 32-bit word (message bit k sits at mask bit k, MSB-first bytes wanted)
-__device__ __forceinline__ uint32_t rev_in_bytes (uint32_t x) { return __builtin_bswap32 (__brev (x)); }
-
-// ------------------------------------------------------------------------------------------
-// 2.4 MS/s slicers.  A data bit that starts `f` fifths of a sample after m[0] is sliced at
-// sample f/5 with the weights of row f%5 (ref: src/demod-2400.c:32-55, 339-412).
-// ------------------------------------------------------------------------------------------
-template <int F>
-__device__ __forceinline__ int slice_const (const int *s)   // s[] = samples as ints, compile-time position
-{
-  constexpr int i = F / 5, r = F % 5;
-  if (r == 0) return 5 * s[i] - 3 * s[i + 1] - 2 * s[i + 2];
-  if (r == 1) return 4 * s[i] - s[i + 1] - 3 * s[i + 2];
-  if (r == 2) return 3 * s[i] + s[i + 1] - 4 * s[i + 2];
-  if (r == 3) return 2 * s[i] + 3 * s[i + 1] - 5 * s[i + 2];
-  return s[i] + 5 * s[i + 1] - 5 * s[i + 2] - s[i + 3];
-}
-template <int R> __device__ __forceinline__ constexpr int corr_weight () { return R == 0 ? 26 : R == 1 ? 38 : R == 2 ? 38 : R == 3 ? 26 : 19; }
-
-// correlate_check for start phase T over the first five bits (ref: src/demod-2400.c:86-129);
-// also returns those five sliced bits (bit 4 = first data bit).
-template <int T>
-__device__ __forceinline__ int check_phase (const int *s, int *five_bits)
-{
-  const int a = slice_const<T> (s), b = slice_const<T + 12> (s), c = slice_const<T + 24> (s),
-            d = slice_const<T + 36> (s), e = slice_const<T + 48> (s);
-  *five_bits = ((a > 0) << 4) | ((b > 0) << 3) | ((c > 0) << 2) | ((d > 0) << 1) | (e > 0);
-  return abs (a * corr_weight<T % 5> ()) + abs (b * corr_weight<(T + 12) % 5> ()) + abs (c * corr_weight<(T + 24) % 5> ()) +
-         abs (d * corr_weight<(T + 36) % 5> ()) + abs (e * corr_weight<(T + 48) % 5> ());
-}
-
-// bytes sliced for a DF (ref: src/demod-2400.c:416-435): 7, 14 or 0 (= give up after byte 0)
-__device__ __forceinline__ int slice_bytes_for_df (int df)
-{
-  const uint32_t short_set = (1u << 0) | (1u << 4) | (1u << 5) | (1u << 11);
-  const uint32_t long_set = (1u << 16) | (1u << 17) | (1u << 18) | (1u << 20) | (1u << 21) | (1u << 24);
-  return ((short_set >> df) & 1) ? kShortBytes : ((long_set >> df) & 1) ? kLongBytes : 0;
-}
-// ref: src/dump1090.c:1427-1432
-__device__ __forceinline__ int msg_bits_for_df (int df)
-{
-  return (df == 16 || df == 17 || df == 19 || df == 20 || df == 21) ? kLongBits : kShortBits;
-}
-
-// Wave-cooperative search of a sorted error table (n <= 4096): two probes per lane.
-__device__ __forceinline__ int table_find (const ErrEntry *tab, int n, uint32_t syn, int lane)
-{
-  if (n <= 0) return -1;
-  const int step = (n + 63) >> 6;
-  const int first = lane * step;
-  const bool le = first < n && tab[first].syndrome <= syn;
-  const u64 m = __ballot (le);
-  if (!m) return -1;
-  const int seg = 63 - __builtin_clzll (m);       // `le` is monotone in the lane index
-  const int idx = seg * step + lane;
-  const bool eq = lane < step && idx < n && tab[idx].syndrome == syn;
-  const u64 h = __ballot (eq);
-  return h ? seg * step + int (__builtin_ctzll (h)) : -1;
-}
 
 // LDS per wave
 struct WaveLds {
@@ -157,121 +29,6 @@ struct WaveLds {
 
 constexpr int kWavesPerBlock = 4;
 
-// ------------------------------------------------------------------------------------------
-// staging: convert samples [a_lo, a_lo + count) into w.tile[0 .. count)
-// ------------------------------------------------------------------------------------------
-template <int CONV> struct RawWords { static constexpr int n = (CONV == kConvUc8Lut || CONV == kConvUc8LutPower) ? 2 : (CONV == kConvUc8Generic || CONV == kConvMagU16) ? 4 : 8; };
-
-// raw IQ of 8 consecutive samples starting at n0 (a multiple of 8, whole chunk inside the shard)
-template <int CONV>
-__device__ __forceinline__ void load_raw8 (const ScanParams &p, long long n0, uint32_t *d)
-{
-  if (CONV == kConvUc8Lut || CONV == kConvUc8LutPower) {
-    // as written: output sample i of a block reads input BYTE i of that block (ref: src/convert.c:19,29)
-    const uint64_t blk = uint64_t (n0) / p.block_samples, i = uint64_t (n0) % p.block_samples;
-    const uint2 v = *reinterpret_cast<const uint2 *> (p.iq + blk * 2 * p.block_samples + i);
-    d[0] = v.x; d[1] = v.y;
-  } else if (CONV == kConvUc8Generic || CONV == kConvMagU16) {
-    const uint4 v = *reinterpret_cast<const uint4 *> (p.iq + 2 * n0);
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-  } else {
-    const uint4 *src = reinterpret_cast<const uint4 *> (p.iq + 4 * n0);
-    const uint4 v0 = src[0], v1 = src[1];
-    d[0] = v0.x; d[1] = v0.y; d[2] = v0.z; d[3] = v0.w; d[4] = v1.x; d[5] = v1.y; d[6] = v1.z; d[7] = v1.w;
-  }
-}
-
-template <int CONV>
-__device__ __forceinline__ uint4 convert_raw8 (const WaveLds &w, const uint32_t *d)
-{
-  if (CONV == kConvMagU16) { uint4 pk; pk.x = d[0]; pk.y = d[1]; pk.z = d[2]; pk.w = d[3]; return pk; }
-  uint16_t out[8];
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    if (CONV == kConvUc8Lut || CONV == kConvUc8LutPower)
-      out[k] = w.lut[(d[k >> 2] >> (8 * (k & 3))) & 0xFF];
-    else if (CONV == kConvUc8Generic) {
-      const uint32_t iqp = d[k >> 1] >> (16 * (k & 1));
-      out[k] = mag_from_float (c_uc8_float[iqp & 0xFF], c_uc8_float[(iqp >> 8) & 0xFF], nullptr);
-    } else {
-      const int I = int (int16_t (d[k] & 0xFFFF)), Q = int (int16_t (d[k] >> 16));
-      if (CONV == kConvSc16Int) out[k] = mag_sc16_int (I, Q);
-      else {
-        const float sc = CONV == kConvSc16Generic ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
-        out[k] = mag_from_float (float (I) * sc, float (Q) * sc, nullptr);
-      }
-    }
-  }
-  uint4 pk;
-  pk.x = out[0] | (uint32_t (out[1]) << 16); pk.y = out[2] | (uint32_t (out[3]) << 16);
-  pk.z = out[4] | (uint32_t (out[5]) << 16); pk.w = out[6] | (uint32_t (out[7]) << 16);
-  return pk;
-}
-
-constexpr int kTileCount = kStrip + kLook2400 + kTilePad;
-constexpr int kTileChunks = kTileCount / 8;
-constexpr int kTileIters = (kTileChunks + 63) / 64;
-
-template <int CONV>
-__device__ __forceinline__ void stage_tile (WaveLds &w, const ScanParams &p, long long a_lo, int lane)
-{
-  const long long N = (long long) (CONV == kConvMagU16 ? p.navail : p.nsamples);
-  constexpr int NW = RawWords<CONV>::n;
-  if (a_lo >= 0 && a_lo + kTileCount <= N) {
-    // interior strip: every load is issued before the first conversion
-    uint32_t raw[kTileIters][NW];
-#pragma unroll
-    for (int it = 0; it < kTileIters; it++) {
-      const int ch = it * 64 + lane;
-      if (ch < kTileChunks) load_raw8<CONV> (p, a_lo + 8 * ch, raw[it]);
-    }
-#pragma unroll
-    for (int it = 0; it < kTileIters; it++) {
-      const int ch = it * 64 + lane;
-      if (ch < kTileChunks) *reinterpret_cast<uint4 *> (&w.tile[8 * ch]) = convert_raw8<CONV> (w, raw[it]);
-    }
-    return;
-  }
-  // first / last strips of the shard: per-sample bounds
-  for (int c = lane * 8; c < kTileCount; c += 64 * 8) {
-    const long long n0 = a_lo + c;
-    uint4 pk;
-    if (n0 >= 0 && n0 + 8 <= N) {
-      uint32_t d[NW];
-      load_raw8<CONV> (p, n0, d);
-      pk = convert_raw8<CONV> (w, d);
-    } else {
-      uint16_t out[8];
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const long long n = n0 + k;
-        uint16_t m = 0;
-        if (n < 0) {
-          if (p.halo && n + (long long) p.ov >= 0) m = p.halo[n + (long long) p.ov];
-        } else if (n < N) {
-          if (CONV == kConvMagU16) m = reinterpret_cast<const uint16_t *> (p.iq)[n];
-          else if (CONV == kConvUc8Lut || CONV == kConvUc8LutPower) {
-            const uint64_t blk = uint64_t (n) / p.block_samples, i = uint64_t (n) % p.block_samples;
-            m = w.lut[p.iq[blk * 2 * p.block_samples + i]];
-          } else if (CONV == kConvUc8Generic) {
-            m = mag_from_float (c_uc8_float[p.iq[2 * n]], c_uc8_float[p.iq[2 * n + 1]], nullptr);
-          } else {
-            const int16_t *s = reinterpret_cast<const int16_t *> (p.iq) + 2 * n;
-            if (CONV == kConvSc16Int) m = mag_sc16_int (s[0], s[1]);
-            else {
-              const float sc = CONV == kConvSc16Generic ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
-              m = mag_from_float (float (s[0]) * sc, float (s[1]) * sc, nullptr);
-            }
-          }
-        }
-        out[k] = m;
-      }
-      pk.x = out[0] | (uint32_t (out[1]) << 16); pk.y = out[2] | (uint32_t (out[3]) << 16);
-      pk.z = out[4] | (uint32_t (out[5]) << 16); pk.w = out[6] | (uint32_t (out[7]) << 16);
-    }
-    *reinterpret_cast<uint4 *> (&w.tile[c]) = pk;
-  }
-}
 
 // ------------------------------------------------------------------------------------------
 // the scan kernel
@@ -297,7 +54,7 @@ void scan2400_kernel (const ScanParams p)
   const long long s0 = P0 - (long long) (CONV == kConvMagU16 ? 0u : p.ov);   // first sample index needed (may be < 0)
   const long long a_lo = (s0 >= 0 ? s0 : s0 - 15) / 16 * 16;  // floor to a multiple of 16
   const int shift = int (s0 - a_lo);                          // V[P0 + x] == tile[x + shift]
-  stage_tile<CONV> (w, p, a_lo, lane);
+  stage_tile<CONV, kStrip + kLook2400 + kTilePad> (w.tile, w.lut, p, a_lo, lane);
   __builtin_amdgcn_s_waitcnt (0xc07f);   // lgkmcnt(0): LDS writes of this wave are done (wave-private data)
   __builtin_amdgcn_wave_barrier ();
 
@@ -845,8 +602,9 @@ struct AcceptLds {
 
 __device__ __forceinline__ uint32_t rdlane (uint32_t v, int l) { return uint32_t (__builtin_amdgcn_readlane (int (v), l)); }
 
+template <int MODE>
 __global__ __launch_bounds__ (256)
-void accept2400_kernel (const AcceptParams p)
+void accept_kernel (const AcceptParams p)
 {
   __shared__ AcceptLds lds[4];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -864,7 +622,7 @@ void accept2400_kernel (const AcceptParams p)
   const uint64_t blk_pos0 = uint64_t (blk) * p.block_samples;
   const uint32_t blk_len = uint32_t (min (uint64_t (p.block_samples), p.nsamples - blk_pos0));
   uint32_t skip_until = 0;                                   // each demod_2400 call starts at j = 0
-  uint32_t st_demod = 0, st_oop = 0, st_good = 0, st_bad = 0, st_fix1 = 0, st_fix2 = 0, st_unk = 0;
+  uint32_t st_demod = 0, st_oop = 0, st_good = 0, st_bad = 0, st_fix1 = 0, st_fix2 = 0, st_unk = 0, st_vp = 0;
 
   for (uint32_t strip = first_strip; strip < last_strip; strip++) {
     const uint32_t cnt = p.counts[strip];
@@ -887,12 +645,19 @@ void accept2400_kernel (const AcceptParams p)
       const uint32_t slot = icao_hash (test_addr);
       bool uncond, need_known, adder;
       if (ap)       { uncond = false; need_known = true; adder = false; }
-      else if (acq) { uncond = iid == 0 && masked == 0; need_known = !uncond; adder = uncond; }
+      else if (acq) {
+        // demod_2400 scores first: a clean DF11 with IID != 0 needs a known address (ref: src/dump1090.c:3332-3338);
+        // demod_2000 goes straight to decode_mode_S_message, which takes any clean DF11 (ref: src/dump1090.c:2471-2490)
+        uncond = masked == 0 && (MODE == 2000 || iid == 0); need_known = !uncond; adder = masked == 0 && iid == 0;
+      }
       else          { uncond = r.crc == 0 || (r.nerr == 1 && !aa_changed); need_known = !uncond; adder = r.crc == 0; }
-      uncond = uncond && have; need_known = need_known && have; adder = adder && have;
+      // demod_2000: records exist for every valid preamble; only some reach decode_mode_S_message
+      const bool decodes = MODE != 2000 || ((r.phase & kInfoDecode) && !(r.phase & kInfoStaticReject));
+      uncond = uncond && have && decodes; need_known = need_known && have && decodes; adder = adder && have && decodes;
       const uint32_t add_val = acq ? aa : (aa | non_icao_flag_dev (r.msg, r.df));
       const uint32_t add_slot = icao_hash (add_val);
-      const uint32_t skip_len = uint32_t (msg_bits_for_df (r.df)) * 12 / 5;           // ref: src/demod-2400.c:514
+      const uint32_t skip_len = MODE == 2000 ? 2u * (8u + r.pad[2]) - 1u                // ref: src/demod-2000.c:997
+                                             : uint32_t (msg_bits_for_df (r.df)) * 12 / 5;   // ref: src/demod-2400.c:514
       const uint32_t c0 = w.cache[slot];
       bool known = have && c0 != 0 && c0 == test_addr;
 
@@ -941,11 +706,21 @@ void accept2400_kernel (const AcceptParams p)
       else if (acq) score = iid == 0 ? (known ? 1600 : 750) / (r.nerr + 1) : (known ? 1000 / (r.nerr + 1) : -1);
       else          score = (known ? 1800 : 1400) / (r.nerr + 1);
       const bool is_acc = (accepted >> lane) & 1;
-      const bool scored = reached && score >= 0;
-      st_oop   += __popcll (__ballot (reached && score > -2));
-      st_demod += __popcll (__ballot (scored));
-      st_bad   += __popcll (__ballot (scored && !is_acc));
-      st_unk   += __popcll (__ballot (scored && !is_acc));      // every reject past the score is "unknown ICAO" (-1)
+      if (MODE == 2000) {
+        score = -1;
+        const bool called = reached && (r.phase & kInfoDecode);                    // decode_mode_S_message ran
+        st_vp    += __popcll (__ballot (reached));                                   // ref: src/demod-2000.c:751
+        const uint32_t inc = reached ? uint32_t (r.phase & kInfoDemodMask) : 0u;     // ref: src/demod-2000.c:848,934
+        st_demod += __popcll (__ballot (inc & 1)) + 2 * __popcll (__ballot (inc & 2));
+        st_bad   += __popcll (__ballot (called && !is_acc));
+        st_unk   += __popcll (__ballot (called && !is_acc && !(r.phase & kInfoStaticReject)));
+      } else {
+        const bool scored = reached && score >= 0;
+        st_oop   += __popcll (__ballot (reached && score > -2));
+        st_demod += __popcll (__ballot (scored));
+        st_bad   += __popcll (__ballot (scored && !is_acc));
+        st_unk   += __popcll (__ballot (scored && !is_acc));      // every reject past the score is "unknown ICAO" (-1)
+      }
       const int ebits = (acq ? (masked ? r.nerr : 0) : ap ? 0 : (r.crc ? r.nerr : 0));
       st_good  += __popcll (__ballot (is_acc && ebits == 0));
       st_fix1  += __popcll (__ballot (is_acc && ebits == 1));
@@ -999,7 +774,7 @@ void accept2400_kernel (const AcceptParams p)
     uint32_t *o = p.blk_stats + size_t (blk) * kBlkStats;
     o[kStDemodulated] = st_demod; o[kStOutOfPhase] = st_oop; o[kStGood] = st_good; o[kStBad] = st_bad;
     o[kStFix1] = st_fix1; o[kStFix2] = st_fix2; o[kStUnknown] = st_unk;
-    o[kStSkippedVp] = w.counter[kStSkippedVp]; o[kStAccepted] = w.counter[kStAccepted];
+    o[kStSkippedVp] = w.counter[kStSkippedVp]; o[kStAccepted] = w.counter[kStAccepted]; o[kStVp] = st_vp;
   }
 }
 
@@ -1088,7 +863,7 @@ void emit2400_kernel (const EmitParams p)
     const int mbits = msg_bits_for_df (r.df);
     const int slen = mbits * 12 / 5;
     u64 acc = 0;                                  // ref: src/demod-2400.c:486-497
-    for (int q = lane; q < slen; q += 64) {
+    for (int q = lane; p.mode != 2000 && q < slen; q += 64) {
       const uint32_t m = CONV == kConvMagU16 ? 0u : mag_of_V<CONV> (p.iq, p.nsamples, p.halo, p.ov, p.block_samples, p.lut256, (long long) P + 19 + q);
       acc += u64 (m * m);
     }
@@ -1098,7 +873,9 @@ void emit2400_kernel (const EmitParams p)
       memset (&o, 0, sizeof o);
       const uint64_t blk = P / p.block_samples, j = P % p.block_samples;
       const uint64_t counter = p.first_sample + blk * p.block_samples;
-      o.timestamp = uint64_t ((double (counter) * 12E6) / double (p.sample_rate)) + j * 5 + r.phase;   // ref: src/infile.c:143, src/demod-2400.c:467
+      const uint64_t block_ts = uint64_t ((double (counter) * 12E6) / double (p.sample_rate));        // ref: src/infile.c:143
+      o.timestamp = p.mode == 2000 ? block_ts + j * 6                                                  // ref: src/demod-2000.c:960
+                                   : block_ts + j * 5 + r.phase;                                       // ref: src/demod-2400.c:467
       for (int b = 0; b < 14; b++) o.msg[b] = r.msg[b];
       const bool ap = r.cls == kClsAP || r.cls == kClsAP2, acq = r.cls == kClsDF11;
       int eb = 0;
@@ -1113,9 +890,10 @@ void emit2400_kernel (const EmitParams p)
       o.crc = r.crc;
       o.score = *reinterpret_cast<const int16_t *> (r.pad);
       o.error_bits = uint8_t (eb);
-      o.phase = r.phase;
+      o.phase = p.mode == 2000 ? uint8_t (0) : r.phase;
       o.block = uint32_t (p.first_sample / p.block_samples + blk);
-      o.sig_level = (double (acc) / 65535.0 / 65535.0) / double (slen);
+      // demod_2000's sig_level is wiped by decode_mode_S_message's memset (ref: src/demod-2000.c:966, src/dump1090.c:2385)
+      o.sig_level = p.mode == 2000 ? 0.0 : (double (acc) / 65535.0 / 65535.0) / double (slen);
       o.j = uint32_t (j);
       out[k] = o;
     }
@@ -1128,9 +906,9 @@ void emit2400_kernel (const EmitParams p)
 // ------------------------------------------------------------------------------------------
 hipError_t upload_constants (const uint32_t *single_bit, const float *uc8_float)
 {
-  hipError_t e = hipMemcpyToSymbol (HIP_SYMBOL (c_single_bit), single_bit, sizeof (uint32_t) * kLongBits);
+  hipError_t e = upload_constants_tu (single_bit, uc8_float);
   if (e != hipSuccess) return e;
-  return hipMemcpyToSymbol (HIP_SYMBOL (c_uc8_float), uc8_float, sizeof (float) * 256);
+  return upload_constants_2000 (single_bit, uc8_float);
 }
 
 hipError_t launch_scan2400 (const ScanParams &p, hipStream_t stream)
@@ -1239,7 +1017,8 @@ hipError_t launch_convert_float (int conv, const uint8_t *iq, uint16_t *mag, siz
 hipError_t launch_accept2400 (const AcceptParams &p, hipStream_t stream)
 {
   if (p.nblocks == 0) return hipSuccess;
-  hipLaunchKernelGGL (accept2400_kernel, dim3 ((p.nblocks + 3) / 4), dim3 (256), 0, stream, p);
+  if (p.mode == 2000) hipLaunchKernelGGL (accept_kernel<2000>, dim3 ((p.nblocks + 3) / 4), dim3 (256), 0, stream, p);
+  else                hipLaunchKernelGGL (accept_kernel<2400>, dim3 ((p.nblocks + 3) / 4), dim3 (256), 0, stream, p);
   return hipGetLastError ();
 }
 
