@@ -4,6 +4,7 @@
 // scan kernel left.  Works on pre-digested records (syndrome + table hit already known).
 #pragma once
 #include <stdint.h>
+#include <functional>
 #include <vector>
 #include "common.h"
 #include "../../include/modes_hip.h"
@@ -47,5 +48,23 @@ void accept_pass_2400 (const Record *records, const uint64_t *pos, size_t n, uin
                        uint64_t first_sample, uint32_t sample_rate, IcaoCache &cache, AcceptStats &st,
                        std::vector<modes_message> &out, std::vector<uint64_t> &out_pos,
                        const uint64_t *vp_bitmap, uint64_t nsamples);
+
+// ---- demod_2000 ----------------------------------------------------------------------------
+// The per-block ordered walk of demod_2000 (ref: src/demod-2000.c:652-1026) over the records scan2000 leaves:
+// one per valid preamble, plus (phase_enhance) its phase-corrected retries, plus Mode A/C replies (mode_AC).
+// `pos[i]` = scan position of the preamble the record belongs to.  The two callbacks are the reference's
+// decode_mode_S_message (returns < 0 to reject; fills msg/addr/error_bits/... of `out`) and
+// modeS_user_message.
+struct Pass2000Stats {
+  uint64_t valid_preamble = 0, demodulated = 0, out_of_phase = 0, demod_modeac = 0, stale = 0;
+};
+struct Pass2000Hooks {
+  // rc of decode_mode_S_message for record r; on success `out` carries msg, msg_bits, msg_type, addr, crc, error_bits
+  std::function<int (const Record &r, uint64_t j, uint8_t corrected, modes_message *out)> decode;
+  std::function<void (const modes_message &m, const Record &r)> emit;
+};
+void accept_pass_2000 (const Record *records, const uint64_t *pos, size_t n, uint32_t block_samples, uint64_t nsamples,
+                       uint64_t first_sample, uint32_t sample_rate, bool phase_enhance, const Pass2000Hooks &hooks,
+                       Pass2000Stats &st);
 
 }  // namespace modes

@@ -30,7 +30,9 @@ constexpr int kLook2000 = 256;        // samples a position may look ahead (16 +
 constexpr int kBack2000 = 16;         // tile slack in front: pre[-1] of the phase correction + 16-sample load alignment
 constexpr int kTile2000 = kStrip + kLook2000 + kBack2000 + 16;
 constexpr int kPlaneWords2000 = (kStrip + kLook2000) / 64;   // 36 words of GT/LT bits
+constexpr int kLook2000PE = 512;      // phase_enhance: the retry behind an accepted message starts up to 239 samples later
 constexpr int kCap2000 = 64;          // records per strip: every valid preamble leaves one
+constexpr int kCap2000PE = 192;       // ... up to three with phase_enhance
 constexpr int kQ2Cap2000 = 256;
 
 // Record.phase carries these for the 2.0 MS/s path
@@ -39,6 +41,11 @@ constexpr uint8_t kInfoDecode = 4;        // reached decode_mode_S_message (msg_
 constexpr uint8_t kInfoStaticReject = 8;  // ... which fails whatever the ICAO cache holds (rc -2 / -3)
 constexpr uint8_t kInfoStale = 16;        // message bytes the slicer never wrote would be read
 constexpr uint8_t kInfoOutOfPhase = 32;   // detect_out_of_phase() != 0 at this preamble
+// bits 6..7: which iteration of demod_2000's loop the record stands for
+constexpr uint8_t kKindPrimary = 0;       // the slice at a valid preamble
+constexpr uint8_t kKindRetrySame = 1;     // phase-corrected retry at the same position (first try not accepted)
+constexpr uint8_t kKindRetryAfter = 2;    // phase-corrected slice behind an accepted message that needed a repair
+constexpr uint8_t kKindModeA = 3;         // Mode A/C reply (Modes.mode_AC)
 
 // Candidate classes (what the ordered accept pass needs to know about a record)
 enum Cls : uint8_t {

@@ -39,6 +39,8 @@ struct DropIn {
   uint32_t *d_bloom_short = nullptr, *d_bloom_long = nullptr;
   int short_n = 0, long_n = 0, dev_fix_bits = -2;
   uint16_t *d_lut = nullptr;
+  uint16_t *d_log10 = nullptr;
+  uint32_t *d_crc_table = nullptr;
   // scratch
   uint8_t *d_in = nullptr;   size_t in_cap = 0;
   uint16_t *d_mag = nullptr; size_t mag_cap = 0;
@@ -96,6 +98,14 @@ bool ensure_ready ()
   build_uc8_byte_lut (lut);
   HIP_OK (hipMalloc (reinterpret_cast<void **> (&g.d_lut), sizeof lut));
   HIP_OK (hipMemcpy (g.d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
+  {
+    std::vector<uint16_t> l10 (65536);
+    build_log10_lut (l10.data ());
+    HIP_OK (hipMalloc (reinterpret_cast<void **> (&g.d_log10), l10.size () * sizeof (uint16_t)));
+    HIP_OK (hipMemcpy (g.d_log10, l10.data (), l10.size () * sizeof (uint16_t), hipMemcpyHostToDevice));
+    HIP_OK (hipMalloc (reinterpret_cast<void **> (&g.d_crc_table), 256 * sizeof (uint32_t)));
+    HIP_OK (hipMemcpy (g.d_crc_table, g.crc.byte_table (), 256 * sizeof (uint32_t), hipMemcpyHostToDevice));
+  }
   HIP_OK (hipMalloc (reinterpret_cast<void **> (&g.d_small), 4 * sizeof (float)));
   HIP_OK (hipMalloc (reinterpret_cast<void **> (&g.d_power), sizeof (unsigned long long)));
   g.ready = true;
@@ -201,18 +211,19 @@ struct HostMm {
   template <typename T> T &at (size_t off) { return *reinterpret_cast<T *> (buf.data () + off); }
 };
 
-bool scan_mag_buf (const mag_buf *mag, std::vector<Record> &recs, uint64_t *vp_total)
+bool scan_mag_buf (const mag_buf *mag, std::vector<Record> &recs, uint64_t *vp_total, int mode = 2400)
 {
   if (!ensure_ready () || !ensure_tables ()) return false;
   HIP_OK (hipSetDevice (g.device));
   const uint32_t mlen = mag->valid_length - mag->overlap;
   const uint32_t nstrips = (mlen + kStrip - 1) / kStrip;
-  const uint32_t cap = (g.bound && g.host.phase_enhance) ? 128 : 32;
+  const bool pe = g.bound && g.host.phase_enhance;
+  const uint32_t cap = mode == 2000 ? uint32_t (pe ? kCap2000PE : kCap2000) : pe ? 128 : 32;
   recs.clear ();
   *vp_total = 0;
   if (nstrips == 0) return true;
   if (!grow (g.d_mag, g.mag_cap, size_t (mag->valid_length) + 64)) return false;
-  if (!grow (g.d_rec, g.rec_cap, size_t (nstrips) * 128)) return false;
+  if (!grow (g.d_rec, g.rec_cap, size_t (nstrips) * kCap2000PE)) return false;
   if (nstrips > g.strip_cap) {
     for (void *p : { (void *) g.d_counts, (void *) g.d_vp, (void *) g.d_bitmap }) if (p) (void) hipFree (p);
     g.d_counts = g.d_vp = nullptr; g.d_bitmap = nullptr; g.strip_cap = 0;
@@ -237,7 +248,9 @@ bool scan_mag_buf (const mag_buf *mag, std::vector<Record> &recs, uint64_t *vp_t
   sp.records = g.d_rec; sp.counts = g.d_counts; sp.vp_counts = g.d_vp; sp.cap = cap; sp.nstrips = nstrips;
   sp.write_records = 1;
   sp.vp_bitmap = g.d_bitmap;
-  HIP_OK (launch_scan2400 (sp, nullptr));
+  sp.log10_lut = g.d_log10; sp.crc_table = g.d_crc_table;
+  sp.mode_ac = g.bound ? g.host.mode_AC : 0;
+  HIP_OK (mode == 2000 ? launch_scan2000 (sp, nullptr) : launch_scan2400 (sp, nullptr));
   std::vector<uint32_t> counts (nstrips), vp (nstrips);
   HIP_OK (hipMemcpyAsync (counts.data (), g.d_counts, nstrips * sizeof (uint32_t), hipMemcpyDeviceToHost, nullptr));
   HIP_OK (hipMemcpyAsync (vp.data (), g.d_vp, nstrips * sizeof (uint32_t), hipMemcpyDeviceToHost, nullptr));
@@ -425,7 +438,62 @@ static void not_built (const char *name)
   fprintf (stderr, "modes_hip: %s\n", modes_last_error ());
 }
 
-void demod_2000 (const mag_buf *) { not_built ("demod_2000"); }
+// ref: src/demod-2000.c:612-1027.  The kernel slices every valid preamble (and its retries); the loop's order,
+// the callbacks and the skip-ahead happen here.
+void demod_2000 (const mag_buf *mag)
+{
+  std::lock_guard<std::mutex> lk (g.mu);
+  std::vector<Record> recs;
+  uint64_t vp = 0;
+  const uint32_t block = g.block_counter++;
+  if (!mag || !mag->data || mag->valid_length < mag->overlap) return;
+  if (!scan_mag_buf (mag, recs, &vp, 2000)) return;
+  const uint32_t mlen = mag->valid_length - mag->overlap;
+  std::vector<uint64_t> pos (recs.size ());
+  for (size_t i = 0; i < recs.size (); i++)
+    pos[i] = (uint64_t (recs[i].pad[0]) | (uint64_t (recs[i].pad[1]) << 8)) * kStrip + recs[i].off;
+
+  const bool have_cb = g.bound && g.host.decode_mode_S_message && g.host.mm_size;
+  HostMm mm;
+  if (have_cb) mm.buf.assign (g.host.mm_size, 0);
+  auto elapsed = [&] (uint64_t ts) {
+    return g.bound && g.host.receiveclock_ms_elapsed ? g.host.receiveclock_ms_elapsed (mag->sample_timestamp, ts)
+                                                      : int64_t ((ts - mag->sample_timestamp) / 12000);
+  };
+  Pass2000Hooks hooks;
+  Pass2000Stats ps;
+  hooks.decode = [&] (const Record &r, uint64_t j, uint8_t, modes_message *out) {
+    if (have_cb) {
+      const uint64_t ts = mag->sample_timestamp + j * 6;                                       // ref: :960
+      mm.at<int> (g.host.off_error_bits) = 0;                                                  // ref: :670
+      mm.at<uint64_t> (g.host.off_timestamp_msg) = ts;
+      mm.at<uint64_t> (g.host.off_sys_timestamp_msg) = mag->sys_timestamp + uint64_t (elapsed (ts));
+      const int rc = g.host.decode_mode_S_message (mm.buf.data (), r.msg);
+      out->error_bits = uint8_t (mm.at<int> (g.host.off_error_bits));
+      return rc;
+    }
+    return (r.phase & kInfoStaticReject) ? -2 : accept_record (r, g.cache, out);
+  };
+  hooks.emit = [&] (const modes_message &m, const Record &r) {
+    if (have_cb) {
+      if (r.cls == kClsModeA) {                                                                 // ref: :677-701
+        mm.at<uint64_t> (g.host.off_timestamp_msg) = mag->sample_timestamp + m.timestamp;
+        mm.at<uint64_t> (g.host.off_sys_timestamp_msg) = mag->sys_timestamp + uint64_t (elapsed (mag->sample_timestamp + m.timestamp));
+        mm.at<double> (g.host.off_sig_level) = m.sig_level;
+        if (g.host.decode_mode_A_message) g.host.decode_mode_A_message (mm.buf.data (), (int (r.msg[0]) << 8) | r.msg[1]);
+      }
+      if (g.host.modeS_user_message) g.host.modeS_user_message (mm.buf.data ());
+    } else {
+      modes_message out = m;
+      out.timestamp += mag->sample_timestamp;
+      out.block = block;
+      g.queue.push_back (out);
+    }
+  };
+  // block geometry of one call: a single block of mlen positions starting at sample counter 0
+  accept_pass_2000 (recs.data (), pos.data (), recs.size (), mlen ? mlen : 1, mlen, 0, 2000000,
+                    g.bound && g.host.phase_enhance, hooks, ps);
+}
 void demod_2400_AC (const mag_buf *) { not_built ("demod_2400_AC"); }
 void demod_8000 (const mag_buf *) { not_built ("demod_8000"); }
 int  demod_8000_alloc (void) { g.d8_allocated = true; return 1; }

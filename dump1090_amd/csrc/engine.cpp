@@ -276,6 +276,7 @@ int run_accept_on_device (modes_engine *e, const ScanParams &sp, uint64_t first_
   e->stats.CRC_single_bit_fix = sum[kStFix1]; e->stats.CRC_two_bits_fix = sum[kStFix2];
   e->stats.CRC_fixed = sum[kStFix1] + sum[kStFix2];
   e->stats.demod_rejected_unknown = sum[kStUnknown];
+  e->stats.demod_modeac = sum[kStModeAC];
   if (e->mode == 2000) e->stats.valid_preamble = sum[kStVp];      // every valid preamble is a record there
   else e->stats.valid_preamble -= sum[kStSkippedVp];
   if (sum[kStAccepted] != nm) return fail (MODES_E_HIP, "accepted-count mismatch (%llu vs %zu)", (unsigned long long) sum[kStAccepted], nm);
@@ -311,8 +312,8 @@ int modes_engine_create (const modes_engine_config *cfg, modes_engine **out)
   *out = nullptr;
   if (cfg->sample_rate != 2400000 && cfg->sample_rate != 2000000)
     return fail (MODES_E_ARG, "sample rate %u: the 2.0 and 2.4 MS/s paths are built so far", cfg->sample_rate);
-  if (cfg->sample_rate == 2000000 && (cfg->phase_enhance || cfg->mode_ac || cfg->host_replay))
-    return fail (MODES_E_ARG, "2.0 MS/s: phase_enhance / mode_ac / host_replay are not built yet");
+  if (cfg->mode_ac && cfg->sample_rate != 2000000)
+    return fail (MODES_E_ARG, "mode_ac: only demod_2000 looks for Mode A/C replies so far");
   const int conv = select_converter (cfg->input_format, cfg->filter_dc != 0, cfg->compute_power != 0);
   if (conv < 0) return fail (MODES_E_ARG, "no suitable converter for format=%d power=%d DC=%d", cfg->input_format,
                              cfg->compute_power, cfg->filter_dc);
@@ -328,7 +329,7 @@ int modes_engine_create (const modes_engine_config *cfg, modes_engine **out)
   e->ov = trailing_samples (cfg->sample_rate);
   e->block_samples = kAsyncBufSize / bytes_per_sample (cfg->input_format);
   e->mode = cfg->sample_rate == 2000000 ? 2000 : 2400;
-  e->cap = e->mode == 2000 ? uint32_t (kCap2000) : cfg->phase_enhance ? 128 : 32;
+  e->cap = e->mode == 2000 ? uint32_t (cfg->phase_enhance ? kCap2000PE : kCap2000) : cfg->phase_enhance ? 128 : 32;
   memset (&e->stats, 0, sizeof e->stats);
   int rc = setup_tables (e);
   if (rc != MODES_OK) { modes_engine_destroy (e); return rc; }
@@ -422,6 +423,30 @@ int modes_engine_run_device (modes_engine *e, const void *d_iq, size_t nbytes, u
     HIP_TRY (hipMemcpyAsync (pos.data (), e->packed_pos.p, nrec * sizeof (uint64_t), hipMemcpyDeviceToHost, stream));
   }
   HIP_TRY (hipStreamSynchronize (stream));
+
+  if (e->mode == 2000) {
+    // ordered walk of demod_2000 on the host (phase_enhance retries / compare mode); all slicing was done by the kernel
+    Pass2000Stats ps;
+    uint64_t good = 0, bad = 0, fix1 = 0, fix2 = 0, unknown = 0;
+    Pass2000Hooks hooks;
+    hooks.decode = [&] (const Record &r, uint64_t, uint8_t, modes_message *out) {
+      const int rc = (r.phase & kInfoStaticReject) ? -2 : accept_record (r, e->cache, out);
+      if (rc < 0) { bad++; if (rc == -1) unknown++; }
+      else if (out->error_bits == 1) fix1++;
+      else if (out->error_bits == 2) fix2++;
+      else good++;
+      return rc;
+    };
+    hooks.emit = [&] (const modes_message &m, const Record &) { e->messages.push_back (m); };
+    accept_pass_2000 (recs.data (), pos.data (), nrec, e->block_samples, sp.nsamples, first_sample, e->cfg.sample_rate,
+                      e->cfg.phase_enhance != 0, hooks, ps);
+    e->stats.valid_preamble = ps.valid_preamble; e->stats.demodulated = ps.demodulated;
+    e->stats.out_of_phase = ps.out_of_phase; e->stats.demod_modeac = ps.demod_modeac;
+    e->stats.CRC_good = good; e->stats.CRC_bad = bad; e->stats.CRC_single_bit_fix = fix1; e->stats.CRC_two_bits_fix = fix2;
+    e->stats.CRC_fixed = fix1 + fix2; e->stats.demod_rejected_unknown = unknown;
+    e->stats.replay_rounds = 0;
+    return MODES_OK;
+  }
 
   // ordered accept pass
   AcceptStats as;

@@ -622,7 +622,7 @@ void accept_kernel (const AcceptParams p)
   const uint64_t blk_pos0 = uint64_t (blk) * p.block_samples;
   const uint32_t blk_len = uint32_t (min (uint64_t (p.block_samples), p.nsamples - blk_pos0));
   uint32_t skip_until = 0;                                   // each demod_2400 call starts at j = 0
-  uint32_t st_demod = 0, st_oop = 0, st_good = 0, st_bad = 0, st_fix1 = 0, st_fix2 = 0, st_unk = 0, st_vp = 0;
+  uint32_t st_demod = 0, st_oop = 0, st_good = 0, st_bad = 0, st_fix1 = 0, st_fix2 = 0, st_unk = 0, st_vp = 0, st_modeac = 0;
 
   for (uint32_t strip = first_strip; strip < last_strip; strip++) {
     const uint32_t cnt = p.counts[strip];
@@ -652,11 +652,14 @@ void accept_kernel (const AcceptParams p)
       }
       else          { uncond = r.crc == 0 || (r.nerr == 1 && !aa_changed); need_known = !uncond; adder = r.crc == 0; }
       // demod_2000: records exist for every valid preamble; only some reach decode_mode_S_message
+      const bool modea = MODE == 2000 && r.cls == kClsModeA;             // emitted as found (ref: src/demod-2000.c:677-701)
       const bool decodes = MODE != 2000 || ((r.phase & kInfoDecode) && !(r.phase & kInfoStaticReject));
-      uncond = uncond && have && decodes; need_known = need_known && have && decodes; adder = adder && have && decodes;
+      if (modea) { uncond = true; need_known = false; adder = false; }
+      uncond = uncond && have && (decodes || modea); need_known = need_known && have && decodes; adder = adder && have && decodes;
       const uint32_t add_val = acq ? aa : (aa | non_icao_flag_dev (r.msg, r.df));
       const uint32_t add_slot = icao_hash (add_val);
-      const uint32_t skip_len = MODE == 2000 ? 2u * (8u + r.pad[2]) - 1u                // ref: src/demod-2000.c:997
+      const uint32_t skip_len = modea ? 50u                                             // ref: src/demod-2000.c:698
+                              : MODE == 2000 ? 2u * (8u + r.pad[2]) - 1u                // ref: src/demod-2000.c:997
                                              : uint32_t (msg_bits_for_df (r.df)) * 12 / 5;   // ref: src/demod-2400.c:514
       const uint32_t c0 = w.cache[slot];
       bool known = have && c0 != 0 && c0 == test_addr;
@@ -708,9 +711,10 @@ void accept_kernel (const AcceptParams p)
       const bool is_acc = (accepted >> lane) & 1;
       if (MODE == 2000) {
         score = -1;
-        const bool called = reached && (r.phase & kInfoDecode);                    // decode_mode_S_message ran
-        st_vp    += __popcll (__ballot (reached));                                   // ref: src/demod-2000.c:751
-        const uint32_t inc = reached ? uint32_t (r.phase & kInfoDemodMask) : 0u;     // ref: src/demod-2000.c:848,934
+        const bool called = reached && !modea && (r.phase & kInfoDecode);          // decode_mode_S_message ran
+        st_vp    += __popcll (__ballot (reached && !modea));                         // ref: src/demod-2000.c:751
+        st_modeac += __popcll (__ballot (reached && modea));                         // ref: src/demod-2000.c:699
+        const uint32_t inc = reached && !modea ? uint32_t (r.phase & kInfoDemodMask) : 0u;   // ref: src/demod-2000.c:848,934
         st_demod += __popcll (__ballot (inc & 1)) + 2 * __popcll (__ballot (inc & 2));
         st_bad   += __popcll (__ballot (called && !is_acc));
         st_unk   += __popcll (__ballot (called && !is_acc && !(r.phase & kInfoStaticReject)));
@@ -722,7 +726,7 @@ void accept_kernel (const AcceptParams p)
         st_unk   += __popcll (__ballot (scored && !is_acc));      // every reject past the score is "unknown ICAO" (-1)
       }
       const int ebits = (acq ? (masked ? r.nerr : 0) : ap ? 0 : (r.crc ? r.nerr : 0));
-      st_good  += __popcll (__ballot (is_acc && ebits == 0));
+      st_good  += __popcll (__ballot (is_acc && ebits == 0 && !modea));
       st_fix1  += __popcll (__ballot (is_acc && ebits == 1));
       st_fix2  += __popcll (__ballot (is_acc && ebits == 2));
       nacc += __popcll (accepted);
@@ -774,7 +778,7 @@ void accept_kernel (const AcceptParams p)
     uint32_t *o = p.blk_stats + size_t (blk) * kBlkStats;
     o[kStDemodulated] = st_demod; o[kStOutOfPhase] = st_oop; o[kStGood] = st_good; o[kStBad] = st_bad;
     o[kStFix1] = st_fix1; o[kStFix2] = st_fix2; o[kStUnknown] = st_unk;
-    o[kStSkippedVp] = w.counter[kStSkippedVp]; o[kStAccepted] = w.counter[kStAccepted]; o[kStVp] = st_vp;
+    o[kStSkippedVp] = w.counter[kStSkippedVp]; o[kStAccepted] = w.counter[kStAccepted]; o[kStVp] = st_vp; o[kStModeAC] = st_modeac;
   }
 }
 
@@ -878,6 +882,18 @@ void emit2400_kernel (const EmitParams p)
                                    : block_ts + j * 5 + r.phase;                                       // ref: src/demod-2400.c:467
       for (int b = 0; b < 14; b++) o.msg[b] = r.msg[b];
       const bool ap = r.cls == kClsAP || r.cls == kClsAP2, acq = r.cls == kClsDF11;
+      if (r.cls == kClsModeA) {                   // ref: src/demod-2000.c:318,677-701, src/dump1090.c:2722-2766
+        const uint32_t code = (uint32_t (r.msg[0]) << 8) | r.msg[1];
+        o.timestamp = block_ts + (j + 1) * 6;
+        o.msg_bits = 16; o.msg_type = 32;
+        o.addr = (code & 0x0000FF7Fu) | kNonIcao;
+        o.score = -1;
+        o.block = uint32_t (p.first_sample / p.block_samples + blk);
+        const int lv = int (r.crc);
+        o.sig_level = double (int (uint32_t (lv) * uint32_t (lv))) / (65535.0 * 65535.0);   // int product as the reference forms it
+        o.j = uint32_t (j);
+        out[k] = o;
+      } else {
       int eb = 0;
       if (acq && (r.crc & 0xFFFF80u)) eb = r.nerr;
       if (!ap && !acq && r.crc) eb = r.nerr;
@@ -896,6 +912,7 @@ void emit2400_kernel (const EmitParams p)
       o.sig_level = p.mode == 2000 ? 0.0 : (double (acc) / 65535.0 / 65535.0) / double (slen);
       o.j = uint32_t (j);
       out[k] = o;
+      }
     }
     k++;
   }

@@ -61,6 +61,24 @@ def envelope(msg: bytes, sample_rate: float, frac: float) -> np.ndarray:
     return np.diff(integ)
 
 
+def envelope_mode_a(code: int, sample_rate: float, frac: float, spi: bool = False) -> np.ndarray:
+    """Mode A/C reply: 0.45 us pulses on a 1.45 us pitch, F1 .. F2 (+ SPI three slots later).
+    `code` uses the reference's bit layout 00:A4:A2:A1:00:B4:B2:B1:00:C4:C2:C1:00:D4:D2:D1 with SPI = 0x0080."""
+    slot_bits = [None, 0x0010, 0x1000, 0x0020, 0x2000, 0x0040, 0x4000, 0, 0x0100, 0x0001, 0x0200, 0x0002, 0x0400,
+                 0x0004, None]                       # F1 C1 A1 C2 A2 C4 A4 X B1 D1 B2 D2 B4 D4 F2
+    on = [True if b is None else bool(code & b) for b in slot_bits]
+    on += [False, False, spi]
+    rate_us = sample_rate * 1e-6
+    n = int(np.ceil(frac + (len(on) * 1.45 + 1) * rate_us)) + 2
+    t = np.arange(n + 1, dtype=np.float64)
+    cum = np.zeros(n + 1)
+    for k, o in enumerate(on):
+        if o:
+            a, b = frac + k * 1.45 * rate_us, frac + (k * 1.45 + 0.45) * rate_us
+            cum += np.clip(t, a, b) - a
+    return np.diff(cum)
+
+
 def quantise(x: np.ndarray, fmt: str) -> np.ndarray:
     """x: complex array, full scale 1.0.  Returns interleaved I,Q in uc8 (uint8) or sc16 (int16)."""
     iq = np.empty(2 * len(x), dtype=np.float64)

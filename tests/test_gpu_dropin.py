@@ -141,3 +141,65 @@ def test_demod_2400_per_block_with_host_callbacks():
     for g, x in zip(got, exp):
         n = int(x["msg_bits"]) // 8
         assert bytes(g["msg"][:n]) == bytes(x["msg"][:n])
+
+
+def test_demod_2000_per_block_builtin_rules():
+    iq, _ = synth.capture(65536 * 3 + 5000, 2.0e6, "sc16", seed=33, frames_per_sec=4000, bitflip1=0.2, ap_fraction=0.3)
+    o = orc.Oracle(2000000, fix_bits=1)
+    o.run_stream(iq, orc.INPUT_SC16, 2000)
+    exp = o.messages()
+    L = da.lib()
+    L.modes_hip_bind(None)
+    L.crc_init(1)
+    da.take_messages()
+    for data, ov, ts in blocks_of(iq, "sc16", rate=2000000):
+        mb = da.make_mag_buf(data, ov, sample_timestamp=ts)
+        L.demod_2000(C.byref(mb))
+    got = da.take_messages()
+    if len(got):
+        got["block"] = (got["block"].astype(np.int64) - int(got["block"][0]) + int(exp["block"][0])).astype(np.uint32)
+    assert len(exp) > 200
+    assert_same_messages(got, exp)
+
+
+def test_demod_2000_with_host_callbacks_and_phase_enhance():
+    """dump1090.c's side played by the oracle; Modes.phase_enhance handed over by the binding."""
+    iq, _ = synth.capture(65536 * 2 + 777, 2.0e6, "sc16", seed=34, frames_per_sec=4000, bitflip1=0.3, bitflip2=0.1,
+                          ap_fraction=0.3, overlap_fraction=0.3)
+    o = orc.Oracle(2000000, fix_bits=2, phase_enhance=True)
+    o.run_stream(iq, orc.INPUT_SC16, 2000)
+    exp = o.messages()
+
+    host = orc.Oracle(2000000, fix_bits=2)
+    OL = orc.lib()
+    seen = []
+    hb = da.HostBinding()
+    hb.mm_size = orc.MSG_DTYPE.itemsize
+    hb.off_timestamp_msg, hb.off_sys_timestamp_msg = 0, 8
+    hb.off_sig_level = orc.MSG_DTYPE.fields["sig_level"][1]
+    hb.off_score = orc.MSG_DTYPE.fields["pad2"][1]
+    hb.off_error_bits = orc.MSG_DTYPE.fields["error_bits"][1]
+    hb.off_AC_flags = orc.MSG_DTYPE.fields["pad2"][1]
+    hb.off_addr = orc.MSG_DTYPE.fields["addr"][1]
+    hb.decode_mode_S_message = da.DECODE_CB(lambda mm, msg: OL.orc_decode_message(host.h, msg, mm))
+    hb.modeS_user_message = da.USER_CB(lambda mm: seen.append(bytes((C.c_char * hb.mm_size).from_address(mm))))
+    hb.receiveclock_ms_elapsed = da.CLOCK_CB(lambda a, b: (b - a) // 12000)
+    hb.fix_bits = 2
+    hb.phase_enhance = 1
+    hb.mode_AC = 0
+    L = da.lib()
+    L.crc_exit()
+    assert L.modes_hip_bind(C.byref(hb)) == 0
+    try:
+        for data, ov, ts in blocks_of(iq, "sc16", rate=2000000):
+            mb = da.make_mag_buf(data, ov, sample_timestamp=ts)
+            L.demod_2000(C.byref(mb))
+    finally:
+        L.modes_hip_bind(None)
+    got = np.frombuffer(b"".join(seen), dtype=orc.MSG_DTYPE)
+    assert len(exp) > 50 and len(got) == len(exp)
+    for f in ("timestamp", "sys_timestamp", "msg_bits", "msg_type", "error_bits", "addr", "crc"):
+        assert np.array_equal(got[f], exp[f]), f
+    for g, x in zip(got, exp):
+        n = int(x["msg_bits"]) // 8
+        assert bytes(g["msg"][:n]) == bytes(x["msg"][:n])

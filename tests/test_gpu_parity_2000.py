@@ -10,13 +10,25 @@ from util import assert_same_messages, oracle_run
 pytestmark = pytest.mark.gpu
 FMT = {"uc8": da.INPUT_UC8, "sc16": da.INPUT_SC16, "sc16q11": da.INPUT_SC16Q11}
 STAT_KEYS = ("valid_preamble", "demodulated", "CRC_good", "CRC_bad", "CRC_single_bit_fix", "CRC_two_bits_fix",
-             "demod_rejected_unknown")
+             "demod_rejected_unknown", "out_of_phase", "demod_modeac")
 
 
 def engine_run(iq, fmt, **kw):
+    """Device accept pass (when the configuration has one) and the host walk must agree."""
+    h = da.Engine(2000000, FMT[fmt], host_replay=True, **kw)
+    h.run_host(iq)
+    got_h, st_h = h.messages(), h.stats()
+    if kw.get("phase_enhance"):
+        return got_h, st_h
     e = da.Engine(2000000, FMT[fmt], **kw)
     e.run_host(iq)
-    return e.messages(), e.stats()
+    got, st = e.messages(), e.stats()
+    assert got.tobytes() == got_h.tobytes()
+    for k in st:
+        if k not in ("replay_rounds", "candidates"):
+            assert st[k] == st_h[k], k
+    assert np.array_equal(e.get_icao(), h.get_icao())
+    return got, st
 
 
 def check(iq, fmt, min_msgs, **kw):
@@ -81,3 +93,54 @@ def test_messages_straddling_block_boundaries():
             x[p:p + len(env)] += 0.3 * np.exp(2j * np.pi * rng.random()) * env
     iq = synth.quantise(x, "sc16")
     check(iq, "sc16", 2 * len(offs) - 4)
+
+
+@pytest.mark.parametrize("seed", [51, 52])
+def test_phase_enhance_retries(seed):
+    """Modes.phase_enhance: phase-corrected retry at a failed preamble and behind a repaired message."""
+    iq, _ = synth.capture(2_000_000, 2.0e6, "sc16", seed=seed, frames_per_sec=4000, bitflip1=0.3, bitflip2=0.1,
+                          ap_fraction=0.25, overlap_fraction=0.3)
+    exp, est = oracle_run(iq, "sc16", rate=2000000, fix_bits=2, phase_enhance=True)
+    got, gst = engine_run(iq, "sc16", fix_bits=2, phase_enhance=True)
+    assert (exp["phase"] == 1).sum() > 10 and est["out_of_phase"] > 100
+    assert_same_messages(got, exp)
+    for k in STAT_KEYS:
+        assert gst[k] == est[k], (k, gst[k], est[k])
+
+
+def mode_a_capture(n, seed, with_mode_s=True):
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.004
+    pos, codes = 500, []
+    while pos < n - 1000:
+        if with_mode_s and rng.random() < 0.4:
+            msg = synth.make_df17(int(rng.integers(0x400000, 0x400008)), bytes(rng.integers(0, 256, 7, dtype=np.uint8)))
+            env = synth.envelope(msg, 2.0e6, rng.random())
+        else:
+            code = int(rng.integers(0, 8)) << 12 | int(rng.integers(0, 8)) << 8 | int(rng.integers(0, 8)) << 4 | int(rng.integers(0, 8))
+            env = synth.envelope_mode_a(code, 2.0e6, rng.random(), spi=rng.random() < 0.2)
+            codes.append(code)
+        amp = 10 ** (rng.uniform(-14, -3) / 20)
+        x[pos:pos + len(env)] += amp * np.exp(2j * np.pi * rng.random()) * env
+        pos += len(env) + int(rng.integers(60, 700))
+    return synth.quantise(x, "sc16"), codes
+
+
+def test_mode_ac_replies():
+    """Modes.mode_AC: detect_mode_A runs ahead of the Mode S preamble test at every position."""
+    iq, codes = mode_a_capture(1_000_000, 61)
+    exp, est = oracle_run(iq, "sc16", rate=2000000, mode_ac=True)
+    got, gst = engine_run(iq, "sc16", mode_ac=True)
+    assert est["demod_modeac"] > 0.3 * len(codes) and (exp["msg_type"] == 17).sum() > 50
+    assert_same_messages(got, exp)
+    for k in STAT_KEYS:
+        assert gst[k] == est[k], (k, gst[k], est[k])
+
+
+def test_mode_ac_with_phase_enhance():
+    iq, _ = mode_a_capture(600_000, 62)
+    exp, est = oracle_run(iq, "sc16", rate=2000000, mode_ac=True, phase_enhance=True, fix_bits=2)
+    got, gst = engine_run(iq, "sc16", mode_ac=True, phase_enhance=True, fix_bits=2)
+    assert_same_messages(got, exp)
+    for k in STAT_KEYS:
+        assert gst[k] == est[k], (k, gst[k], est[k])

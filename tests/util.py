@@ -24,7 +24,9 @@ def assert_same_messages(got, exp, sig_rtol=1e-5):
     assert np.array_equal(got["msg_bits"].astype(np.int64), exp["msg_bits"].astype(np.int64))
     assert np.array_equal(got["msg_type"].astype(np.int64), exp["msg_type"].astype(np.int64))
     assert np.array_equal(got["error_bits"].astype(np.int64), exp["error_bits"].astype(np.int64))
-    assert np.array_equal(got["crc"], exp["crc"])
+    # a Mode A/C message (type 32) leaves mm.CRC as the previous decode_mode_S_message call set it: not a field of it
+    ms = exp["msg_type"] != 32
+    assert np.array_equal(got["crc"][ms], exp["crc"][ms])
     assert np.array_equal(got["score"].astype(np.int64), exp["score"].astype(np.int64))
     assert np.array_equal(got["phase"].astype(np.int64), exp["phase"].astype(np.int64))
     assert np.array_equal(got["block"].astype(np.int64), exp["block"].astype(np.int64))
@@ -34,7 +36,7 @@ def assert_same_messages(got, exp, sig_rtol=1e-5):
     mask = np.where(exp["msg_type"] == 18, 0xFFFFFF, 0xFFFFFFFF).astype(np.uint32)
     assert np.array_equal(got["addr"] & mask, exp["addr"] & mask)
     nb = exp["msg_bits"] // 8
-    for k in (7, 14):
+    for k in (2, 7, 14):
         sel = nb == k
         assert np.array_equal(got["msg"][sel][:, :k], exp["msg"][sel][:, :k])
     np.testing.assert_allclose(got["sig_level"], exp["sig_level"], rtol=sig_rtol, atol=0)
