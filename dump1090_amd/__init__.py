@@ -116,6 +116,8 @@ def lib():
         L.modes_engine_messages.restype = C.c_void_p
         L.modes_engine_messages.argtypes = [C.c_void_p]
         L.modes_engine_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.modes_engine_block_power.restype = C.c_size_t
+        L.modes_engine_block_power.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.modes_engine_tail_halo.restype = C.c_void_p
         L.modes_engine_tail_halo.argtypes = [C.c_void_p]
         L.modes_convert_device.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(ConvertState),
@@ -201,6 +203,14 @@ class Engine:
             return np.zeros(0, dtype=MESSAGE_DTYPE)
         buf = (C.c_char * (n * MESSAGE_DTYPE.itemsize)).from_address(self.L.modes_engine_messages(self.h))
         return np.frombuffer(buf, dtype=MESSAGE_DTYPE).copy()
+
+    def block_power(self):
+        """mean_power of every block of the last run (only computed with mode_ac at 2.4 MS/s)."""
+        n = self.L.modes_engine_block_power(self.h, None, 0)
+        a = np.zeros(n, dtype=np.float64)
+        if n:
+            self.L.modes_engine_block_power(self.h, a.ctypes.data_as(C.c_void_p), n)
+        return a
 
     def stats(self):
         s = Stats()

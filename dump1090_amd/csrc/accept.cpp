@@ -254,4 +254,29 @@ void accept_pass_2000 (const Record *rec, const uint64_t *pos, size_t n, uint32_
   }
 }
 
+void accept_pass_2400ac (const Record *rec, const uint64_t *pos, size_t n, uint32_t B, uint64_t first_sample,
+                         uint32_t sample_rate, std::vector<modes_message> &out)
+{
+  uint64_t cur_block = ~0ull, skip_until = 0;
+  for (size_t i = 0; i < n; i++) {
+    const uint64_t blk = pos[i] / B, f1 = pos[i] % B;
+    if (blk != cur_block) { cur_block = blk; skip_until = 0; }
+    if (f1 < skip_until) continue;
+    const uint64_t counter = first_sample + blk * B;
+    const uint64_t block_ts = uint64_t ((double (counter) * 12E6) / double (sample_rate));   // ref: src/infile.c:143
+    modes_message mm;
+    memset (&mm, 0, sizeof mm);
+    const uint32_t code = (uint32_t (rec[i].msg[0]) << 8) | rec[i].msg[1];
+    mm.timestamp = block_ts + rec[i].crc / 5;                      // f2_clock / 5 (ref: src/demod-2400AC.c:211)
+    mm.msg[0] = rec[i].msg[0]; mm.msg[1] = rec[i].msg[1];
+    mm.msg_bits = 16; mm.msg_type = 32;                            // ref: src/dump1090.c:2722-2766
+    mm.addr = (code & 0x0000FF7Fu) | kNonIcao;
+    mm.score = -1;
+    mm.block = uint32_t (first_sample / B + blk);
+    mm.j = uint32_t (f1);
+    out.push_back (mm);
+    skip_until = f1 + 20 * 87 / 25 + 1;                            // ref: :226 and the loop's increment
+  }
+}
+
 }  // namespace modes

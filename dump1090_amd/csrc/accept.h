@@ -67,4 +67,10 @@ void accept_pass_2000 (const Record *records, const uint64_t *pos, size_t n, uin
                        uint64_t first_sample, uint32_t sample_rate, bool phase_enhance, const Pass2000Hooks &hooks,
                        Pass2000Stats &st);
 
+// ---- demod_2400_AC ----
+// The loop of demod_2400_AC over the hits the kernel found (ref: src/demod-2400AC.c:58,206-226): a hit is taken
+// unless it lies inside the 69 samples skipped behind the previous one of the same block.
+void accept_pass_2400ac (const Record *records, const uint64_t *pos, size_t n, uint32_t block_samples,
+                         uint64_t first_sample, uint32_t sample_rate, std::vector<modes_message> &out);
+
 }  // namespace modes

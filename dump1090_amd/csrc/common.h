@@ -47,6 +47,8 @@ constexpr uint8_t kKindRetrySame = 1;     // phase-corrected retry at the same p
 constexpr uint8_t kKindRetryAfter = 2;    // phase-corrected slice behind an accepted message that needed a repair
 constexpr uint8_t kKindModeA = 3;         // Mode A/C reply (Modes.mode_AC)
 
+constexpr int kLookAC = 80;           // demod_2400_AC reads up to f1 + 69 (ref: src/demod-2400AC.c:145-173)
+
 // Candidate classes (what the ordered accept pass needs to know about a record)
 enum Cls : uint8_t {
   kClsAP = 0,      // DF0/4/5/16/24: address = CRC, score 1000 / -1      (ref: src/dump1090.c:3302-3307)
@@ -100,6 +102,8 @@ struct ScanParams {
   const uint16_t *log10_lut;       // 65536 entries (ref: src/dump1090.c:410-423)
   const uint32_t *crc_table;       // 256 entries (ref: src/crc.c:43-54)
   int32_t         mode_ac;
+  // demod_2400_AC
+  const uint32_t *noise_level;     // [blocks]: (unsigned)((mean_power + sqrt(mean_power - mean_level^2)) * 65535 + 0.5)
 };
 
 }  // namespace modes

@@ -41,6 +41,7 @@ struct DropIn {
   uint16_t *d_lut = nullptr;
   uint16_t *d_log10 = nullptr;
   uint32_t *d_crc_table = nullptr;
+  uint32_t *d_noise = nullptr;
   // scratch
   uint8_t *d_in = nullptr;   size_t in_cap = 0;
   uint16_t *d_mag = nullptr; size_t mag_cap = 0;
@@ -211,7 +212,8 @@ struct HostMm {
   template <typename T> T &at (size_t off) { return *reinterpret_cast<T *> (buf.data () + off); }
 };
 
-bool scan_mag_buf (const mag_buf *mag, std::vector<Record> &recs, uint64_t *vp_total, int mode = 2400)
+// mode: 2400 / 2000 = the Mode S scan of that demodulator, 24001 = demod_2400_AC
+bool scan_mag_buf (const mag_buf *mag, std::vector<Record> &recs, uint64_t *vp_total, int mode = 2400, uint32_t noise_level = 0)
 {
   if (!ensure_ready () || !ensure_tables ()) return false;
   HIP_OK (hipSetDevice (g.device));
@@ -250,7 +252,13 @@ bool scan_mag_buf (const mag_buf *mag, std::vector<Record> &recs, uint64_t *vp_t
   sp.vp_bitmap = g.d_bitmap;
   sp.log10_lut = g.d_log10; sp.crc_table = g.d_crc_table;
   sp.mode_ac = g.bound ? g.host.mode_AC : 0;
-  HIP_OK (mode == 2000 ? launch_scan2000 (sp, nullptr) : launch_scan2400 (sp, nullptr));
+  if (mode == 24001) {
+    if (!g.d_noise) HIP_OK (hipMalloc (reinterpret_cast<void **> (&g.d_noise), sizeof (uint32_t)));
+    HIP_OK (hipMemcpyAsync (g.d_noise, &noise_level, sizeof noise_level, hipMemcpyHostToDevice, nullptr));
+    sp.noise_level = g.d_noise;
+    HIP_OK (launch_scanac2400 (sp, nullptr));
+  } else
+    HIP_OK (mode == 2000 ? launch_scan2000 (sp, nullptr) : launch_scan2400 (sp, nullptr));
   std::vector<uint32_t> counts (nstrips), vp (nstrips);
   HIP_OK (hipMemcpyAsync (counts.data (), g.d_counts, nstrips * sizeof (uint32_t), hipMemcpyDeviceToHost, nullptr));
   HIP_OK (hipMemcpyAsync (vp.data (), g.d_vp, nstrips * sizeof (uint32_t), hipMemcpyDeviceToHost, nullptr));
@@ -494,7 +502,44 @@ void demod_2000 (const mag_buf *mag)
   accept_pass_2000 (recs.data (), pos.data (), recs.size (), mlen ? mlen : 1, mlen, 0, 2000000,
                     g.bound && g.host.phase_enhance, hooks, ps);
 }
-void demod_2400_AC (const mag_buf *) { not_built ("demod_2400_AC"); }
+// ref: src/demod-2400AC.c:25-228
+void demod_2400_AC (const mag_buf *mag)
+{
+  std::lock_guard<std::mutex> lk (g.mu);
+  if (!mag || !mag->data || mag->valid_length < mag->overlap) return;
+  // noise_level as the reference forms it from the block's mean_power / mean_level (ref: :34-35)
+  const double noise_stddev = sqrt (mag->mean_power - mag->mean_level * mag->mean_level);
+  const double nv = (mag->mean_power + noise_stddev) * 65535 + 0.5;
+  const uint32_t noise_level = (nv < 9.2e18 && nv > -9.2e18) ? uint32_t (uint64_t ((long long) nv)) : 0u;
+  std::vector<Record> recs;
+  uint64_t vp = 0;
+  if (!scan_mag_buf (mag, recs, &vp, 24001, noise_level)) return;
+  const uint32_t mlen = mag->valid_length - mag->overlap;
+  std::vector<uint64_t> pos (recs.size ());
+  for (size_t i = 0; i < recs.size (); i++)
+    pos[i] = (uint64_t (recs[i].pad[0]) | (uint64_t (recs[i].pad[1]) << 8)) * kStrip + recs[i].off;
+  std::vector<modes_message> out;
+  accept_pass_2400ac (recs.data (), pos.data (), recs.size (), mlen ? mlen : 1, 0, 2400000, out);
+  const bool have_cb = g.bound && g.host.mm_size && g.host.modeS_user_message;
+  HostMm mm;
+  if (have_cb) mm.buf.assign (g.host.mm_size, 0);                                              // memset at :46
+  const uint32_t block = g.block_counter ? g.block_counter - 1 : 0;                            // same block as the demod_2400 call before
+  for (modes_message &m : out) {
+    const uint64_t ts = mag->sample_timestamp + m.timestamp;
+    if (have_cb) {
+      const int64_t ms = g.host.receiveclock_ms_elapsed ? g.host.receiveclock_ms_elapsed (mag->sample_timestamp, ts)
+                                                        : int64_t ((ts - mag->sample_timestamp) / 12000);
+      mm.at<uint64_t> (g.host.off_timestamp_msg) = ts;
+      mm.at<uint64_t> (g.host.off_sys_timestamp_msg) = mag->sys_timestamp + uint64_t (ms);
+      if (g.host.decode_mode_A_message) g.host.decode_mode_A_message (mm.buf.data (), (int (m.msg[0]) << 8) | m.msg[1]);
+      g.host.modeS_user_message (mm.buf.data ());
+    } else {
+      m.timestamp = ts;
+      m.block = block;
+      g.queue.push_back (m);
+    }
+  }
+}
 void demod_8000 (const mag_buf *) { not_built ("demod_8000"); }
 int  demod_8000_alloc (void) { g.d8_allocated = true; return 1; }
 void demod_8000_free (void) { g.d8_allocated = false; }

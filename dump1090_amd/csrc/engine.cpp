@@ -130,6 +130,9 @@ struct modes_engine {
   DevBuf<uint64_t> chunk_sum, chunk_vp, chunk_ovf, packed_pos, offsets, rssi_pos, rssi_sum, vp_bitmap;
   DevBuf<uint8_t> staging;                  // for run_host
   DevBuf<uint16_t> tail;
+  DevBuf<double> block_power;
+  DevBuf<uint32_t> noise_level;
+  size_t nblocks_power = 0;
   unsigned long long *d_stats = nullptr;
   uint32_t cap = 0;
   // results
@@ -312,8 +315,6 @@ int modes_engine_create (const modes_engine_config *cfg, modes_engine **out)
   *out = nullptr;
   if (cfg->sample_rate != 2400000 && cfg->sample_rate != 2000000)
     return fail (MODES_E_ARG, "sample rate %u: the 2.0 and 2.4 MS/s paths are built so far", cfg->sample_rate);
-  if (cfg->mode_ac && cfg->sample_rate != 2000000)
-    return fail (MODES_E_ARG, "mode_ac: only demod_2000 looks for Mode A/C replies so far");
   const int conv = select_converter (cfg->input_format, cfg->filter_dc != 0, cfg->compute_power != 0);
   if (conv < 0) return fail (MODES_E_ARG, "no suitable converter for format=%d power=%d DC=%d", cfg->input_format,
                              cfg->compute_power, cfg->filter_dc);
@@ -347,6 +348,7 @@ void modes_engine_destroy (modes_engine *e)
   e->snap_in.release (); e->delta.release (); e->chunk_last.release (); e->chunk_entry.release (); e->acc_counts.release ();
   e->blk_stats.release (); e->small_u32.release (); e->d_messages.release ();
   e->rssi_sum.release (); e->staging.release (); e->tail.release (); e->vp_bitmap.release ();
+  e->block_power.release (); e->noise_level.release ();
   if (e->tabs.short_tab) (void) hipFree (e->tabs.short_tab);
   if (e->tabs.long_tab) (void) hipFree (e->tabs.long_tab);
   if (e->tabs.lut256) (void) hipFree (e->tabs.lut256);
@@ -372,7 +374,7 @@ int modes_engine_get_icao (modes_engine *e, uint32_t *slots)
   return MODES_OK;
 }
 
-int modes_engine_run_device (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t first_sample,
+static int run_device_inner (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t first_sample,
                              const uint16_t *d_halo, void *stream_v)
 {
   if (!e || (!d_iq && nbytes)) return fail (MODES_E_ARG, "null argument");
@@ -483,6 +485,70 @@ int modes_engine_run_device (modes_engine *e, const void *d_iq, size_t nbytes, u
   return MODES_OK;
 }
 
+// demod_2400_AC behind demod_2400 on every block (BASELINE.json configs[4]; ref: src/demod-2400AC.c:25-228).
+// The kernel answers "does a reply start here" for every position; the 69-sample skip behind a hit is applied here on
+// the hit list, and each block's replies are queued behind the block's Mode S messages.
+static int run_mode_ac_2400 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t first_sample,
+                             const uint16_t *d_halo, hipStream_t stream)
+{
+  ScanParams sp;
+  int rc = fill_scan_params (e, d_iq, nbytes, d_halo, &sp);
+  if (rc != MODES_OK) return rc;
+  if (sp.nstrips == 0) return MODES_OK;
+  const uint32_t B = e->block_samples;
+  const uint32_t nblocks = uint32_t ((sp.nsamples + B - 1) / B);
+  if ((rc = e->block_power.reserve (nblocks)) != MODES_OK) return rc;
+  if ((rc = e->noise_level.reserve (nblocks)) != MODES_OK) return rc;
+  HIP_TRY (launch_block_power (sp, nblocks, e->block_power.p, stream));
+  e->nblocks_power = nblocks;
+  HIP_TRY (launch_noise_level (e->block_power.p, nblocks, e->noise_level.p, stream));
+  sp.noise_level = e->noise_level.p;
+  HIP_TRY (launch_scanac2400 (sp, stream));
+  uint64_t *d_totals = reinterpret_cast<uint64_t *> (e->d_stats);
+  HIP_TRY (launch_count_scan (e->counts.p, e->vp_counts.p, sp.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p,
+                              d_totals, stream));
+  unsigned long long st[3];
+  HIP_TRY (hipMemcpyAsync (st, d_totals, sizeof st, hipMemcpyDeviceToHost, stream));
+  HIP_TRY (hipStreamSynchronize (stream));
+  if (st[2]) return fail (MODES_E_OVERFLOW, "%llu strips overflowed their Mode A/C slots", st[2]);
+  const size_t nrec = size_t (st[0]);
+  if (!nrec) return MODES_OK;
+  if ((rc = e->packed.reserve (nrec + 1)) != MODES_OK) return rc;
+  if ((rc = e->packed_pos.reserve (nrec + 1)) != MODES_OK) return rc;
+  if ((rc = e->offsets.reserve (sp.nstrips)) != MODES_OK) return rc;
+  HIP_TRY (launch_gather (e->counts.p, sp.nstrips, e->chunk_sum.p, e->records.p, e->cap, e->packed.p, e->packed_pos.p,
+                          e->offsets.p, stream));
+  std::vector<Record> recs (nrec);
+  std::vector<uint64_t> pos (nrec);
+  HIP_TRY (hipMemcpyAsync (recs.data (), e->packed.p, nrec * sizeof (Record), hipMemcpyDeviceToHost, stream));
+  HIP_TRY (hipMemcpyAsync (pos.data (), e->packed_pos.p, nrec * sizeof (uint64_t), hipMemcpyDeviceToHost, stream));
+  HIP_TRY (hipStreamSynchronize (stream));
+
+  std::vector<modes_message> ac;
+  accept_pass_2400ac (recs.data (), pos.data (), nrec, B, first_sample, e->cfg.sample_rate, ac);
+  e->stats.valid_preamble += ac.size ();                       // ref: src/demod-2400AC.c:215-216
+  e->stats.demod_modeac += ac.size ();
+  // per block: Mode S messages first, then the block's replies
+  std::vector<modes_message> merged;
+  merged.reserve (e->messages.size () + ac.size ());
+  size_t a = 0, s = 0;
+  while (a < ac.size () || s < e->messages.size ()) {
+    if (a == ac.size () || (s < e->messages.size () && e->messages[s].block <= ac[a].block)) merged.push_back (e->messages[s++]);
+    else merged.push_back (ac[a++]);
+  }
+  e->messages.swap (merged);
+  return MODES_OK;
+}
+
+int modes_engine_run_device (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t first_sample,
+                             const uint16_t *d_halo, void *stream_v)
+{
+  int rc = run_device_inner (e, d_iq, nbytes, first_sample, d_halo, stream_v);
+  if (rc == MODES_OK && e->mode == 2400 && e->cfg.mode_ac)
+    rc = run_mode_ac_2400 (e, d_iq, nbytes, first_sample, d_halo, static_cast<hipStream_t> (stream_v));
+  return rc;
+}
+
 int modes_engine_run_host (modes_engine *e, const void *iq, size_t nbytes, uint64_t first_sample)
 {
   if (!e || (!iq && nbytes)) return fail (MODES_E_ARG, "null argument");
@@ -525,6 +591,17 @@ int modes_engine_get_stats (const modes_engine *e, modes_stats *out)
   if (!e || !out) return fail (MODES_E_ARG, "null argument");
   *out = e->stats;
   return MODES_OK;
+}
+
+size_t modes_engine_block_power (modes_engine *e, double *out, size_t max)
+{
+  if (!e) return 0;
+  const size_t n = e->nblocks_power;
+  if (out && n) {
+    if (hipSetDevice (e->cfg.device) != hipSuccess) return 0;
+    if (hipMemcpy (out, e->block_power.p, (n < max ? n : max) * sizeof (double), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  }
+  return n;
 }
 
 const uint16_t *modes_engine_tail_halo (const modes_engine *e) { return e ? e->tail.p : nullptr; }

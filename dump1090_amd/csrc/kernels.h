@@ -9,6 +9,11 @@ hipError_t launch_scan2400 (const ScanParams &p, hipStream_t stream);
 // kernels_2000.hip
 hipError_t upload_constants_2000 (const uint32_t *single_bit, const float *uc8_float);
 hipError_t launch_scan2000 (const ScanParams &p, hipStream_t stream);
+// kernels_ac.hip
+hipError_t upload_constants_ac (const uint32_t *single_bit, const float *uc8_float);
+hipError_t launch_scanac2400 (const ScanParams &p, hipStream_t stream);
+hipError_t launch_noise_level (const double *mean_power, uint32_t nblocks, uint32_t *noise_level, hipStream_t stream);
+hipError_t launch_block_power (const ScanParams &p, uint32_t nblocks, double *mean_power, hipStream_t stream);
 hipError_t launch_convert (int conv, const uint8_t *iq, uint16_t *mag, size_t n, const uint16_t *lut256,
                            unsigned long long *power_u64, hipStream_t stream);
 hipError_t launch_rssi2400 (int conv, const uint8_t *iq, uint64_t nsamples, const uint16_t *halo, uint32_t ov,

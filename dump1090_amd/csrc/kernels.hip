@@ -925,7 +925,9 @@ hipError_t upload_constants (const uint32_t *single_bit, const float *uc8_float)
 {
   hipError_t e = upload_constants_tu (single_bit, uc8_float);
   if (e != hipSuccess) return e;
-  return upload_constants_2000 (single_bit, uc8_float);
+  e = upload_constants_2000 (single_bit, uc8_float);
+  if (e != hipSuccess) return e;
+  return upload_constants_ac (single_bit, uc8_float);
 }
 
 hipError_t launch_scan2400 (const ScanParams &p, hipStream_t stream)

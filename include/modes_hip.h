@@ -221,6 +221,9 @@ int  modes_engine_time_scan (modes_engine *e, const void *d_iq, size_t nbytes, i
 size_t               modes_engine_num_messages (const modes_engine *e);
 const modes_message *modes_engine_messages (const modes_engine *e);      /* host memory */
 int                  modes_engine_get_stats (const modes_engine *e, modes_stats *out);
+/* mag_buf.mean_power of every block of the last run, as the selected converter reports it (ref: src/infile.c:168);
+ * filled when mode_ac is set at 2.4 MS/s.  Copies up to `max` values, returns the number of blocks. */
+size_t               modes_engine_block_power (modes_engine *e, double *out, size_t max);
 /* the last block's trailing `overlap` magnitudes (device memory), to pass as d_halo of the next shard */
 const uint16_t      *modes_engine_tail_halo (const modes_engine *e);
 
