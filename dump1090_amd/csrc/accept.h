@@ -73,4 +73,17 @@ void accept_pass_2000 (const Record *records, const uint64_t *pos, size_t n, uin
 void accept_pass_2400ac (const Record *records, const uint64_t *pos, size_t n, uint32_t block_samples,
                          uint64_t first_sample, uint32_t sample_rate, std::vector<modes_message> &out);
 
+// ---- demod_8000 ----
+// The ordered part of demod_8000 over the completed match windows (ref: src/demod-8000.c:368-488): score the
+// window's candidates against the live ICAO cache, keep the best (first wins ties), decode, emit.
+struct Pass8000Stats {
+  uint64_t valid_preamble = 0, demodulated = 0, CRC_good = 0, CRC_bad = 0, CRC_single_bit_fix = 0, CRC_two_bits_fix = 0,
+           rejected_unknown = 0;
+};
+// rssi_pos / rssi_len / rssi_msg: scan position, length and message index of every signal-level sum still to be formed
+void accept_pass_8000 (const D8Window *win, size_t nwin, const Record *rec, uint32_t block_samples, int bshift, uint64_t T,
+                       uint32_t ov, uint64_t first_sample, uint32_t sample_rate, IcaoCache &cache, Pass8000Stats &st,
+                       std::vector<modes_message> &out, std::vector<uint64_t> &rssi_pos, std::vector<uint32_t> &rssi_len,
+                       std::vector<uint32_t> &rssi_msg);
+
 }  // namespace modes

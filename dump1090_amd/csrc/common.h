@@ -49,6 +49,15 @@ constexpr uint8_t kKindModeA = 3;         // Mode A/C reply (Modes.mode_AC)
 
 constexpr int kLookAC = 80;           // demod_2400_AC reads up to f1 + 69 (ref: src/demod-2400AC.c:145-173)
 
+// ---- 8 MS/s path (demod_8000; ref: src/demod-8000.c:14-62) ----------------------------
+constexpr int kD8LookAhead = 544, kD8LookBack = 1384, kD8Overlap = 1928, kD8Win = 168, kD8Net = 113;
+constexpr int kD8Ambig = 4576;           // 2*max > 3*av is settled without av above this: av <= 50000000 >> 14 = 3051
+constexpr int kD8SaneMax = 50000000;
+constexpr int kD8StripSteps = 256;       // bit steps (8 samples each) per wave of the trigger kernel
+constexpr int kD8ChunkSteps = 65536;     // bit steps per chunk of the window-chain kernels
+constexpr int kD8WinCap = kD8ChunkSteps / kD8Net + 2;
+constexpr int kD8Cand = 32;              // candidate messages per window: 16 bit shifts x (short, long)
+
 // Candidate classes (what the ordered accept pass needs to know about a record)
 enum Cls : uint8_t {
   kClsAP = 0,      // DF0/4/5/16/24: address = CRC, score 1000 / -1      (ref: src/dump1090.c:3302-3307)
@@ -128,6 +137,38 @@ struct AcceptParams {
   const uint64_t *vp_bitmap;     // may be null
   uint32_t       *changed;       // set to 1 when a delta entry differs from the previous round
   int32_t         mode;          // 2400 or 2000: which demodulator's loop is replayed
+};
+
+// One completed match window of demod_8000 (ref: src/demod-8000.c:331-420)
+struct D8Window {
+  int64_t  s;            // bit step at which the window opened
+  int64_t  g_short;      // first sample (look-ahead domain) of the 72-bit search string
+  int64_t  g_long;       // ... of the 128-bit search string
+  uint32_t nrec;         // candidates that are not -2 whatever the ICAO cache holds
+  uint32_t pad;
+};
+
+struct D8Params {
+  ScanParams      sp;            // input geometry (iq, nsamples, conv, ov, block_samples, halo, lut256, tables)
+  uint64_t        T;             // samples processed: sum over blocks of (valid - overlap) & ~7
+  uint64_t        nsteps;        // T / 8
+  int32_t         bshift;        // block_samples == 1 << bshift (63: one block)
+  const int32_t  *dprev;         // [1928] differences that precede the stream (a previous call's tail), or null = zeros
+  uint64_t       *trig;          // [nsteps/64 + 2] bit n: the search would start a window at step n
+  uint64_t       *amb;           // same shape: 0 < max <= kD8Ambig, needs the running average
+  uint32_t       *amb_count;     // [1] number of ambiguous steps
+  uint32_t       *p0;            // [nsteps] phase[0] per step   (written only when write_arrays)
+  uint32_t       *mx;            // [nsteps] max phase per step  (written only when write_arrays)
+  int32_t         write_arrays;
+  int32_t         acc0;          // d8m_phase_av_acc at the start of the stream
+  int64_t         pending;       // step (< 0) at which a window carried in from a previous call opened, or 1 = none
+  uint8_t        *table;         // [nchunks][128] chain exit for every entry offset
+  uint8_t        *entry;         // [nchunks + 1]
+  int64_t        *win_start;     // [nchunks][kD8WinCap]
+  uint32_t       *win_count;     // [nchunks]
+  D8Window       *windows;       // [nchunks][kD8WinCap]
+  Record         *records;       // [nchunks][kD8WinCap][kD8Cand]
+  uint32_t        nchunks;
 };
 
 struct EmitParams {

@@ -265,4 +265,27 @@ __device__ __forceinline__ void stage_tile (uint16_t *tile, const uint16_t *lut,
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// one magnitude of the virtual stream V[x] (x = scan position domain), any converter, slow path
+// ------------------------------------------------------------------------------------------
+template <int CONV>
+__device__ __forceinline__ uint16_t mag_of_V (const uint8_t *iq, uint64_t nsamples, const uint16_t *halo, uint32_t ov,
+                                              uint32_t block_samples, const uint16_t *lut256, long long x)
+{
+  if (CONV == kConvMagU16) return (x >= 0 && uint64_t (x) < nsamples) ? reinterpret_cast<const uint16_t *> (iq)[x] : uint16_t (0);
+  const long long n = x - (long long) ov;
+  if (n < 0) return (halo && x >= 0) ? halo[x] : uint16_t (0);
+  if (uint64_t (n) >= nsamples) return 0;
+  if (CONV == kConvUc8Lut || CONV == kConvUc8LutPower) {
+    const uint64_t blk = uint64_t (n) / block_samples, i = uint64_t (n) % block_samples;
+    return lut256[iq[blk * 2 * block_samples + i]];
+  }
+  if (CONV == kConvUc8Generic) return mag_from_float (c_uc8_float[iq[2 * n]], c_uc8_float[iq[2 * n + 1]], nullptr);
+  const int16_t *s = reinterpret_cast<const int16_t *> (iq) + 2 * n;
+  if (CONV == kConvSc16Int) return mag_sc16_int (s[0], s[1]);
+  const float sc = CONV == kConvSc16Generic ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
+  return mag_from_float (float (s[0]) * sc, float (s[1]) * sc, nullptr);
+}
+
+
 }  // namespace modes

@@ -133,6 +133,13 @@ struct modes_engine {
   DevBuf<double> block_power;
   DevBuf<uint32_t> noise_level;
   size_t nblocks_power = 0;
+  // 8 MS/s
+  DevBuf<uint64_t> d8_trig, d8_amb, d8_off;
+  DevBuf<uint32_t> d8_p0, d8_mx, d8_win_count, d8_chunk_rec;
+  DevBuf<uint8_t> d8_table, d8_entry;
+  DevBuf<int64_t> d8_win_start, d8_small;
+  DevBuf<D8Window> d8_windows, d8_win_packed;
+  DevBuf<Record> d8_records, d8_rec_packed;
   unsigned long long *d_stats = nullptr;
   uint32_t cap = 0;
   // results
@@ -313,8 +320,8 @@ int modes_engine_create (const modes_engine_config *cfg, modes_engine **out)
 {
   if (!cfg || !out) return fail (MODES_E_ARG, "null argument");
   *out = nullptr;
-  if (cfg->sample_rate != 2400000 && cfg->sample_rate != 2000000)
-    return fail (MODES_E_ARG, "sample rate %u: the 2.0 and 2.4 MS/s paths are built so far", cfg->sample_rate);
+  if (cfg->sample_rate != 2400000 && cfg->sample_rate != 2000000 && cfg->sample_rate != 8000000)
+    return fail (MODES_E_ARG, "sample rate %u: the reference demodulates 2.0, 2.4 and 8.0 MS/s", cfg->sample_rate);
   const int conv = select_converter (cfg->input_format, cfg->filter_dc != 0, cfg->compute_power != 0);
   if (conv < 0) return fail (MODES_E_ARG, "no suitable converter for format=%d power=%d DC=%d", cfg->input_format,
                              cfg->compute_power, cfg->filter_dc);
@@ -329,7 +336,7 @@ int modes_engine_create (const modes_engine_config *cfg, modes_engine **out)
   e->conv = conv;
   e->ov = trailing_samples (cfg->sample_rate);
   e->block_samples = kAsyncBufSize / bytes_per_sample (cfg->input_format);
-  e->mode = cfg->sample_rate == 2000000 ? 2000 : 2400;
+  e->mode = cfg->sample_rate == 2000000 ? 2000 : cfg->sample_rate == 8000000 ? 8000 : 2400;
   e->cap = e->mode == 2000 ? uint32_t (cfg->phase_enhance ? kCap2000PE : kCap2000) : cfg->phase_enhance ? 128 : 32;
   memset (&e->stats, 0, sizeof e->stats);
   int rc = setup_tables (e);
@@ -349,6 +356,10 @@ void modes_engine_destroy (modes_engine *e)
   e->blk_stats.release (); e->small_u32.release (); e->d_messages.release ();
   e->rssi_sum.release (); e->staging.release (); e->tail.release (); e->vp_bitmap.release ();
   e->block_power.release (); e->noise_level.release ();
+  e->d8_trig.release (); e->d8_amb.release (); e->d8_off.release (); e->d8_p0.release (); e->d8_mx.release ();
+  e->d8_win_count.release (); e->d8_chunk_rec.release (); e->d8_table.release (); e->d8_entry.release ();
+  e->d8_win_start.release (); e->d8_small.release (); e->d8_windows.release (); e->d8_win_packed.release ();
+  e->d8_records.release (); e->d8_rec_packed.release ();
   if (e->tabs.short_tab) (void) hipFree (e->tabs.short_tab);
   if (e->tabs.long_tab) (void) hipFree (e->tabs.long_tab);
   if (e->tabs.lut256) (void) hipFree (e->tabs.lut256);
@@ -540,9 +551,128 @@ static int run_mode_ac_2400 (modes_engine *e, const void *d_iq, size_t nbytes, u
   return MODES_OK;
 }
 
+// demod_8000 over a whole recording (ref: src/demod-8000.c:143-523); see kernels_8000.hip for the decomposition.
+static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t first_sample, const uint16_t *d_halo,
+                     hipStream_t stream)
+{
+  if (first_sample % e->block_samples) return fail (MODES_E_ARG, "first_sample must be a multiple of the block length");
+  HIP_TRY (hipSetDevice (e->cfg.device));
+  e->messages.clear ();
+  memset (&e->stats, 0, sizeof e->stats);
+  const uint32_t B = e->block_samples;
+  const uint64_t nsamples = nbytes / bytes_per_sample (e->cfg.input_format);
+  const uint64_t nfull = nsamples / B, rest = nsamples - nfull * B;
+  const uint64_t T = nfull * B + (rest & ~7ull);                  // `mlen &= ~7` per block (ref: :203)
+  D8Params q;
+  memset (&q, 0, sizeof q);
+  ScanParams &sp = q.sp;
+  sp.iq = static_cast<const uint8_t *> (d_iq); sp.nsamples = nsamples; sp.halo = d_halo; sp.ov = e->ov;
+  sp.block_samples = B; sp.conv = e->conv;
+  sp.short_tab = e->tabs.short_tab; sp.short_n = e->tabs.short_n; sp.long_tab = e->tabs.long_tab; sp.long_n = e->tabs.long_n;
+  sp.lut256 = e->tabs.lut256; sp.bloom_short = e->tabs.bloom_short; sp.bloom_long = e->tabs.bloom_long;
+  sp.crc_table = e->tabs.crc_table;
+  q.T = T; q.nsteps = T / 8;
+  q.bshift = 0; while ((1u << q.bshift) < B) q.bshift++;
+  q.acc0 = 0; q.pending = 1;
+  if (q.nsteps == 0) return MODES_OK;
+  const uint32_t nchunks = uint32_t ((q.nsteps + kD8ChunkSteps - 1) / kD8ChunkSteps);
+  q.nchunks = nchunks;
+  const size_t nwords = size_t (q.nsteps / 64 + 64);
+  int rc;
+  if ((rc = e->d8_trig.reserve (nwords)) != MODES_OK) return rc;
+  if ((rc = e->d8_amb.reserve (nwords)) != MODES_OK) return rc;
+  if ((rc = e->d8_table.reserve (size_t (nchunks) * 128)) != MODES_OK) return rc;
+  if ((rc = e->d8_entry.reserve (nchunks + 1)) != MODES_OK) return rc;
+  if ((rc = e->d8_win_start.reserve (size_t (nchunks) * kD8WinCap)) != MODES_OK) return rc;
+  if ((rc = e->d8_win_count.reserve (nchunks)) != MODES_OK) return rc;
+  if ((rc = e->d8_chunk_rec.reserve (nchunks)) != MODES_OK) return rc;
+  if ((rc = e->d8_windows.reserve (size_t (nchunks) * kD8WinCap)) != MODES_OK) return rc;
+  if ((rc = e->d8_records.reserve (size_t (nchunks) * kD8WinCap * kD8Cand)) != MODES_OK) return rc;
+  if ((rc = e->d8_small.reserve (16)) != MODES_OK) return rc;
+  if ((rc = e->d8_off.reserve (2 * size_t (nchunks) + 2)) != MODES_OK) return rc;
+  q.trig = e->d8_trig.p; q.amb = e->d8_amb.p; q.table = e->d8_table.p; q.entry = e->d8_entry.p;
+  q.win_start = e->d8_win_start.p; q.win_count = e->d8_win_count.p; q.windows = e->d8_windows.p; q.records = e->d8_records.p;
+  // d8_small: [0..3] pre-window list, [4] pending window, [5] amb count (low half) , [6] last ambiguous step + 1
+  long long *d_pre = reinterpret_cast<long long *> (e->d8_small.p);
+  long long *d_pending = d_pre + 4;
+  q.amb_count = reinterpret_cast<uint32_t *> (d_pre + 5);
+  unsigned long long *d_limit = reinterpret_cast<unsigned long long *> (d_pre + 6);
+  const long long init[8] = { 0, 0, 0, 0, 1, 0, 0, 0 };
+  HIP_TRY (hipMemcpyAsync (d_pre, init, sizeof init, hipMemcpyHostToDevice, stream));
+  HIP_TRY (hipMemsetAsync (q.trig, 0, nwords * sizeof (uint64_t), stream));
+  HIP_TRY (hipMemsetAsync (q.amb, 0, nwords * sizeof (uint64_t), stream));
+  HIP_TRY (launch_d8_trig (q, stream));
+  HIP_TRY (launch_d8_last_amb (q.amb, nwords, d_limit, stream));
+  unsigned long long limit = 0;
+  HIP_TRY (hipMemcpyAsync (&limit, d_limit, sizeof limit, hipMemcpyDeviceToHost, stream));
+  HIP_TRY (hipStreamSynchronize (stream));
+  if (limit) {
+    // some steps sit in the band where the trigger depends on the running average: form it, in order, up to the last one
+    if ((rc = e->d8_p0.reserve (size_t (q.nsteps) + 64)) != MODES_OK) return rc;
+    if ((rc = e->d8_mx.reserve (size_t (q.nsteps) + 64)) != MODES_OK) return rc;
+    q.p0 = e->d8_p0.p; q.mx = e->d8_mx.p; q.write_arrays = 1;
+    HIP_TRY (launch_d8_trig (q, stream));
+    q.write_arrays = 0;
+    HIP_TRY (launch_d8_acc (q, limit, nullptr, stream));
+  }
+  HIP_TRY (launch_d8_chain (q, 0ull, 0ll, d_pre, d_pending, stream));
+  HIP_TRY (launch_d8_windows (q, stream));
+  HIP_TRY (launch_d8_count (q, e->d8_chunk_rec.p, stream));
+  std::vector<uint32_t> wc (nchunks), rcnt (nchunks);
+  HIP_TRY (hipMemcpyAsync (wc.data (), e->d8_win_count.p, nchunks * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
+  HIP_TRY (hipMemcpyAsync (rcnt.data (), e->d8_chunk_rec.p, nchunks * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
+  HIP_TRY (hipStreamSynchronize (stream));
+  std::vector<uint64_t> off (2 * size_t (nchunks) + 2);
+  uint64_t nwin = 0, nrec = 0;
+  for (uint32_t c = 0; c < nchunks; c++) {
+    if (wc[c] > uint32_t (kD8WinCap)) return fail (MODES_E_OVERFLOW, "chunk %u holds %u windows (cap %d)", c, wc[c], kD8WinCap);
+    off[c] = nwin; off[nchunks + 1 + c] = nrec;
+    nwin += wc[c]; nrec += rcnt[c];
+  }
+  e->stats.candidates = nrec;
+  if (!nwin) return MODES_OK;
+  if ((rc = e->d8_win_packed.reserve (nwin)) != MODES_OK) return rc;
+  if ((rc = e->d8_rec_packed.reserve (nrec + 1)) != MODES_OK) return rc;
+  HIP_TRY (hipMemcpyAsync (e->d8_off.p, off.data (), off.size () * sizeof (uint64_t), hipMemcpyHostToDevice, stream));
+  HIP_TRY (launch_d8_gather (q, e->d8_off.p, e->d8_off.p + nchunks + 1, e->d8_win_packed.p, e->d8_rec_packed.p, stream));
+  std::vector<D8Window> wins (nwin);
+  std::vector<Record> recs (nrec + 1);
+  HIP_TRY (hipMemcpyAsync (wins.data (), e->d8_win_packed.p, nwin * sizeof (D8Window), hipMemcpyDeviceToHost, stream));
+  if (nrec) HIP_TRY (hipMemcpyAsync (recs.data (), e->d8_rec_packed.p, nrec * sizeof (Record), hipMemcpyDeviceToHost, stream));
+  HIP_TRY (hipStreamSynchronize (stream));
+
+  Pass8000Stats ps;
+  std::vector<uint64_t> rpos; std::vector<uint32_t> rlen, rmsg;
+  accept_pass_8000 (wins.data (), nwin, recs.data (), B, q.bshift, T, e->ov, first_sample, e->cfg.sample_rate, e->cache, ps,
+                    e->messages, rpos, rlen, rmsg);
+  e->stats.valid_preamble = ps.valid_preamble; e->stats.demodulated = ps.demodulated;
+  e->stats.CRC_good = ps.CRC_good; e->stats.CRC_bad = ps.CRC_bad; e->stats.CRC_single_bit_fix = ps.CRC_single_bit_fix;
+  e->stats.CRC_two_bits_fix = ps.CRC_two_bits_fix; e->stats.CRC_fixed = ps.CRC_single_bit_fix + ps.CRC_two_bits_fix;
+  e->stats.demod_rejected_unknown = ps.rejected_unknown;
+  const size_t nr = rpos.size ();
+  if (nr) {                                                       // signal level (ref: :469-484)
+    std::vector<uint64_t> sums (nr);
+    for (size_t i = 0; i < nr; i++) rpos[i] -= 19;                // the shared kernel sums from position + 19
+    if ((rc = e->rssi_pos.reserve (nr)) != MODES_OK) return rc;
+    if ((rc = e->rssi_len.reserve (nr)) != MODES_OK) return rc;
+    if ((rc = e->rssi_sum.reserve (nr)) != MODES_OK) return rc;
+    HIP_TRY (hipMemcpyAsync (e->rssi_pos.p, rpos.data (), nr * sizeof (uint64_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY (hipMemcpyAsync (e->rssi_len.p, rlen.data (), nr * sizeof (uint32_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY (launch_rssi2400 (e->conv, sp.iq, sp.nsamples, sp.halo, sp.ov, sp.block_samples, sp.lut256, e->rssi_pos.p,
+                              e->rssi_len.p, e->rssi_sum.p, uint32_t (nr), stream));
+    HIP_TRY (hipMemcpyAsync (sums.data (), e->rssi_sum.p, nr * sizeof (uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY (hipStreamSynchronize (stream));
+    for (size_t i = 0; i < nr; i++)
+      e->messages[rmsg[i]].sig_level = (double (sums[i]) / 65535.0 / 65535.0) / double (rlen[i]);
+  }
+  return MODES_OK;
+}
+
 int modes_engine_run_device (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t first_sample,
                              const uint16_t *d_halo, void *stream_v)
 {
+  if (!e || (!d_iq && nbytes)) return fail (MODES_E_ARG, "null argument");
+  if (e->mode == 8000) return run_8000 (e, d_iq, nbytes, first_sample, d_halo, static_cast<hipStream_t> (stream_v));
   int rc = run_device_inner (e, d_iq, nbytes, first_sample, d_halo, stream_v);
   if (rc == MODES_OK && e->mode == 2400 && e->cfg.mode_ac)
     rc = run_mode_ac_2400 (e, d_iq, nbytes, first_sample, d_halo, static_cast<hipStream_t> (stream_v));

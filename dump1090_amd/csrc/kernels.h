@@ -14,6 +14,18 @@ hipError_t upload_constants_ac (const uint32_t *single_bit, const float *uc8_flo
 hipError_t launch_scanac2400 (const ScanParams &p, hipStream_t stream);
 hipError_t launch_noise_level (const double *mean_power, uint32_t nblocks, uint32_t *noise_level, hipStream_t stream);
 hipError_t launch_block_power (const ScanParams &p, uint32_t nblocks, double *mean_power, hipStream_t stream);
+// kernels_8000.hip
+hipError_t upload_constants_8000 (const uint32_t *single_bit, const float *uc8_float);
+hipError_t launch_d8_trig (const D8Params &q, hipStream_t stream);
+hipError_t launch_d8_acc (const D8Params &q, uint64_t limit, int32_t *acc_out, hipStream_t stream);
+hipError_t launch_d8_last_amb (const uint64_t *amb, uint64_t nwords, unsigned long long *limit, hipStream_t stream);
+hipError_t launch_d8_chain (const D8Params &q, unsigned long long trig_tail, long long search0, long long *pre,
+                            long long *pending_out, hipStream_t stream);
+hipError_t launch_d8_windows (const D8Params &q, hipStream_t stream);
+hipError_t launch_d8_tail (const D8Params &q, int32_t *dnext, hipStream_t stream);
+hipError_t launch_d8_count (const D8Params &q, uint32_t *chunk_rec, hipStream_t stream);
+hipError_t launch_d8_gather (const D8Params &q, const uint64_t *win_off, const uint64_t *rec_off, D8Window *win_out,
+                             Record *rec_out, hipStream_t stream);
 hipError_t launch_convert (int conv, const uint8_t *iq, uint16_t *mag, size_t n, const uint16_t *lut256,
                            unsigned long long *power_u64, hipStream_t stream);
 hipError_t launch_rssi2400 (int conv, const uint8_t *iq, uint64_t nsamples, const uint16_t *halo, uint32_t ov,

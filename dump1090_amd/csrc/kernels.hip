@@ -322,28 +322,6 @@ void convert_kernel (const uint8_t *iq, uint16_t *mag, size_t n, const uint16_t 
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// one magnitude of the virtual stream V[x] (x = scan position domain), any converter, slow path
-// ------------------------------------------------------------------------------------------
-template <int CONV>
-__device__ __forceinline__ uint16_t mag_of_V (const uint8_t *iq, uint64_t nsamples, const uint16_t *halo, uint32_t ov,
-                                              uint32_t block_samples, const uint16_t *lut256, long long x)
-{
-  if (CONV == kConvMagU16) return (x >= 0 && uint64_t (x) < nsamples) ? reinterpret_cast<const uint16_t *> (iq)[x] : uint16_t (0);
-  const long long n = x - (long long) ov;
-  if (n < 0) return (halo && x >= 0) ? halo[x] : uint16_t (0);
-  if (uint64_t (n) >= nsamples) return 0;
-  if (CONV == kConvUc8Lut || CONV == kConvUc8LutPower) {
-    const uint64_t blk = uint64_t (n) / block_samples, i = uint64_t (n) % block_samples;
-    return lut256[iq[blk * 2 * block_samples + i]];
-  }
-  if (CONV == kConvUc8Generic) return mag_from_float (c_uc8_float[iq[2 * n]], c_uc8_float[iq[2 * n + 1]], nullptr);
-  const int16_t *s = reinterpret_cast<const int16_t *> (iq) + 2 * n;
-  if (CONV == kConvSc16Int) return mag_sc16_int (s[0], s[1]);
-  const float sc = CONV == kConvSc16Generic ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
-  return mag_from_float (float (s[0]) * sc, float (s[1]) * sc, nullptr);
-}
-
 // Sum of squared magnitudes V[pos[i] + 19 .. + len[i]) for accepted messages
 // (ref: src/demod-2400.c:486-497).  One wave per message.
 template <int CONV>
@@ -927,7 +905,9 @@ hipError_t upload_constants (const uint32_t *single_bit, const float *uc8_float)
   if (e != hipSuccess) return e;
   e = upload_constants_2000 (single_bit, uc8_float);
   if (e != hipSuccess) return e;
-  return upload_constants_ac (single_bit, uc8_float);
+  e = upload_constants_ac (single_bit, uc8_float);
+  if (e != hipSuccess) return e;
+  return upload_constants_8000 (single_bit, uc8_float);
 }
 
 hipError_t launch_scan2400 (const ScanParams &p, hipStream_t stream)

@@ -1,0 +1,602 @@
+// gfx950 kernels of the 8 MS/s path (demod_8000, ref: src/demod-8000.c:143-565).
+//
+// The reference walks the magnitude stream once, one bit period (8 samples) per step:
+//   * dbuf[j] = m[j] - m[j+4]                                  (4-sample difference, ref: :208-215)
+//   * phase[i] = sum of |dbuf| over 56 taps 8 samples apart     (sliding, one sum per sample phase, ref: :235-271)
+//   * a slow average of phase[0] decides when a match window opens (ref: :275-302)
+//   * a window records 168 steps, then the peak of the match is searched for a message with 16 one-bit shifts of
+//     a short and a long candidate (ref: :331-420), and the walk resumes 55 steps back (ref: :493-496).
+// Restated as functions of the step index n, which is what lets it run wide:
+//   * phase[i](n) is a difference of two column prefix sums                      -> d8_trig_kernel, d8_window_kernel
+//   * the average is a recurrence over n that no backtrack disturbs (the restore puts back exactly the value it had
+//     at that step); it only matters where 0 < max <= 4576, because av <= 50000000 >> 14 -> d8_acc_kernel (rare)
+//   * window openings are the chain s' = first trigger at or after s + 113        -> d8_chain_* kernels
+//   * each completed window is independent work                                  -> d8_window_kernel
+// What needs the ICAO cache (which candidate wins, accept) is left to the ordered pass over the windows' records.
+// "ref:" citations are relative to the reference's root.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "common.h"
+#include "device_common.h"
+
+namespace modes {
+
+namespace {
+
+constexpr int kW8 = 4;                                           // waves per workgroup
+constexpr int kTrigRows = kD8StripSteps + 56;                    // 312 rows of 8 differences per strip
+constexpr int kTrigTile = 2520;                                  // 8 * 312 + 4 + 15 alignment, rounded to 8
+constexpr int kWinRows = 241;                                    // rows s-4 .. s+236 of a window
+constexpr int kWinTile = 1952;                                   // 8 * 241 + 4 + 15, rounded to 8
+
+// D'[g]: the difference stream in the look-ahead domain of the reference's `dbuf = d8m_dbuf + D8M_LOOK_BACK`
+// (ref: :208-222): D'[g] = D[g - 544].  tile[x - x0] = V[x], the magnitudes in scan-position coordinates.
+__device__ __forceinline__ int dprime_tile (const D8Params &q, const uint16_t *tile, long long x0, long long g)
+{
+  if (g < kD8LookAhead) return (q.dprev && g >= -kD8LookBack) ? q.dprev[g + kD8LookBack] : 0;
+  const uint64_t P = uint64_t (g - kD8LookAhead);
+  if (P >= q.T) return 0;
+  const uint64_t B = q.sp.block_samples;
+  const uint64_t blk = q.bshift >= 63 ? 0 : P >> q.bshift;
+  const uint64_t j = P - blk * B;
+  const uint64_t mlen = min (B, q.T - blk * B);
+  int v = tile[(long long) P - x0];
+  if (j + 4 < mlen) v -= tile[(long long) P + 4 - x0];             // the last 4 of a block stay raw (ref: :210-215)
+  return v;
+}
+
+// column-wise exclusive prefix sums of c[rows][8] in place, rows = 8 * per; total goes to row `rows`
+__device__ __forceinline__ void column_prefix (uint32_t *c, uint32_t *tot, int per, int lane)
+{
+  const int i = lane & 7, seg = lane >> 3;
+  uint32_t run = 0;
+  for (int r = seg * per; r < seg * per + per; r++) { const uint32_t v = c[r * 8 + i]; c[r * 8 + i] = run; run += v; }
+  tot[lane] = run;
+  __builtin_amdgcn_s_waitcnt (0xc07f);
+  __builtin_amdgcn_wave_barrier ();
+  uint32_t offset = 0;
+  for (int s = 0; s < seg; s++) offset += tot[s * 8 + i];
+  for (int r = seg * per; r < seg * per + per; r++) c[r * 8 + i] += offset;
+  if (seg == 7) c[8 * per * 8 + i] = offset + run;
+  __builtin_amdgcn_s_waitcnt (0xc07f);
+  __builtin_amdgcn_wave_barrier ();
+}
+
+struct TrigLds {
+  uint16_t tile[kTrigTile];
+  uint32_t c[(kTrigRows + 1) * 8];
+  uint32_t tot[64];
+  uint16_t lut[256];
+};
+
+struct WinLds {
+  uint16_t tile[kWinTile];
+  int32_t  dw[kWinRows * 8 + 8];
+  uint32_t c[(224 + 1) * 8];
+  uint32_t tot[64];
+  int32_t  match[kD8Win];
+  uint8_t  par[kD8Win + 8];
+  uint16_t lut[256];
+};
+
+__device__ __forceinline__ int len_by_type8 (int df) { return (df == 16 || df == 17 || df == 19 || df == 20 || df == 21) ? kLongBits : kShortBits; }
+
+__device__ __forceinline__ uint32_t crc_words (const uint32_t *tab, const uint32_t *w, int nbytes)
+{
+  uint32_t rem = 0;
+  for (int i = 0; i < nbytes - 3; i++) {
+    const uint32_t b = (w[i >> 2] >> (8 * (i & 3))) & 0xFF;
+    rem = ((rem << 8) ^ tab[b ^ ((rem >> 16) & 0xFF)]) & 0xFFFFFFu;
+  }
+  const int n = nbytes;
+  const uint32_t b3 = (w[(n - 3) >> 2] >> (8 * ((n - 3) & 3))) & 0xFF, b2 = (w[(n - 2) >> 2] >> (8 * ((n - 2) & 3))) & 0xFF,
+                 b1 = (w[(n - 1) >> 2] >> (8 * ((n - 1) & 3))) & 0xFF;
+  return rem ^ (b3 << 16) ^ (b2 << 8) ^ b1;
+}
+
+__device__ __forceinline__ int table_lookup8 (const ErrEntry *tab, int n, uint32_t syn)
+{
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (tab[mid].syndrome < syn) lo = mid + 1; else hi = mid;
+  }
+  return (lo < n && tab[lo].syndrome == syn) ? lo : -1;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// per step: the 8 sliding sums, their maximum, and whether the search would open a window there
+// ---------------------------------------------------------------------------------------------
+template <int CONV>
+__global__ __launch_bounds__ (64 * kW8)
+void d8_trig_kernel (const D8Params q)
+{
+  __shared__ TrigLds lds[kW8];
+  const int lane = lane_id ();
+  const int wv = threadIdx.x >> 6;
+  TrigLds &w = lds[wv];
+  const uint64_t nstrips = (q.nsteps + kD8StripSteps - 1) / kD8StripSteps;
+  const uint64_t strip = uint64_t (blockIdx.x) * kW8 + wv;
+  if (strip >= nstrips) return;
+  for (int i = lane; i < 256; i += 64) w.lut[i] = q.sp.lut256 ? q.sp.lut256[i] : uint16_t (0);
+
+  const long long n0 = (long long) strip * kD8StripSteps;
+  const long long g0 = 8 * (n0 + 1);                                        // first difference of row 0
+  const long long xlo = g0 - kD8LookAhead;                                  // its scan position (may be < 0)
+  const long long slo = xlo - (long long) (CONV == kConvMagU16 ? 0u : q.sp.ov);
+  const long long a_lo = (slo >= 0 ? slo : slo - 15) / 16 * 16;
+  const long long x0 = xlo - (slo - a_lo);
+  stage_tile<CONV, kTrigTile> (w.tile, w.lut, q.sp, a_lo, lane);
+  __builtin_amdgcn_s_waitcnt (0xc07f);
+  __builtin_amdgcn_wave_barrier ();
+
+  for (int idx = lane; idx < kTrigRows * 8; idx += 64) {
+    const int d = dprime_tile (q, w.tile, x0, g0 + idx);
+    w.c[idx] = uint32_t (d < 0 ? -d : d);
+  }
+  __builtin_amdgcn_s_waitcnt (0xc07f);
+  __builtin_amdgcn_wave_barrier ();
+  column_prefix (w.c, w.tot, kTrigRows / 8, lane);
+
+  uint32_t namb = 0;
+#pragma unroll
+  for (int it = 0; it < kD8StripSteps / 64; it++) {
+    const int s = it * 64 + lane;
+    const long long n = n0 + s;
+    const uint4 a0 = *reinterpret_cast<const uint4 *> (&w.c[s * 8]), a1 = *reinterpret_cast<const uint4 *> (&w.c[s * 8 + 4]);
+    const uint4 b0 = *reinterpret_cast<const uint4 *> (&w.c[(s + 56) * 8]), b1 = *reinterpret_cast<const uint4 *> (&w.c[(s + 56) * 8 + 4]);
+    const uint32_t ph0 = b0.x - a0.x;
+    uint32_t mxv = max (max (max (ph0, b0.y - a0.y), max (b0.z - a0.z, b0.w - a0.w)),
+                        max (max (b1.x - a1.x, b1.y - a1.y), max (b1.z - a1.z, b1.w - a1.w)));
+    const bool valid = uint64_t (n) < q.nsteps;
+    const bool on = valid && mxv > uint32_t (kD8Ambig);
+    const bool am = valid && mxv > 0 && mxv <= uint32_t (kD8Ambig);
+    const u64 bon = __ballot (on), bam = __ballot (am);
+    if (lane == 0) { q.trig[(n0 >> 6) + it] = bon; q.amb[(n0 >> 6) + it] = bam; }
+    if (q.write_arrays && valid) { q.p0[n] = ph0; q.mx[n] = mxv; }
+    namb += __popcll (bam);
+  }
+  if (lane == 0 && namb) atomicAdd (q.amb_count, namb);
+}
+
+// ---------------------------------------------------------------------------------------------
+// the slow average, only when some step needs it (ref: :275-288, 302).  One wave: all lanes fetch, lane 0 recurs.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__ (64)
+void d8_acc_kernel (const D8Params q, uint64_t limit, int32_t *acc_out)
+{
+  __shared__ uint32_t p0s[1024], mxs[1024];
+  __shared__ u64 ambs[16], trs[16];
+  const int lane = threadIdx.x;
+  int acc = q.acc0;
+  for (uint64_t base = 0; base < limit; base += 1024) {
+    const int cnt = int (min (uint64_t (1024), limit - base));
+    for (int i = lane; i < cnt; i += 64) { p0s[i] = q.p0[base + i]; mxs[i] = q.mx[base + i]; }
+    if (lane < 16) { ambs[lane] = q.amb[(base >> 6) + lane]; trs[lane] = 0; }
+    __syncthreads ();
+    if (lane == 0) {
+      for (int i = 0; i < cnt; i++) {
+        acc += int (p0s[i]);
+        if (acc > kD8SaneMax || acc < -kD8SaneMax) acc = 0;
+        const int av = acc >> 14;
+        acc -= av;
+        if ((ambs[i >> 6] >> (i & 63)) & 1)
+          if (int (mxs[i]) * 2 > av * 3) trs[i >> 6] |= 1ull << (i & 63);
+      }
+    }
+    __syncthreads ();
+    if (lane < 16 && trs[lane]) q.trig[(base >> 6) + lane] |= trs[lane];
+    __syncthreads ();
+  }
+  if (lane == 0 && acc_out) *acc_out = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// window openings: s' = first trigger at or after s + 113
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long first_trig (const u64 *bm, int nwords, long long rel)
+{
+  int wi = int (rel >> 6);
+  if (wi >= nwords) return -1;
+  u64 word = bm[wi] & (~0ull << (rel & 63));
+  while (!word) { if (++wi >= nwords) return -1; word = bm[wi]; }
+  return (long long) wi * 64 + __builtin_ctzll (word);
+}
+
+// table[chunk][r] = where the search stands, relative to the end of the chunk, when it entered at offset r
+__global__ __launch_bounds__ (128)
+void d8_chain_table_kernel (const D8Params q)
+{
+  __shared__ u64 bm[kD8ChunkSteps / 64];
+  const uint32_t c = blockIdx.x;
+  const long long n_lo = (long long) c * kD8ChunkSteps, n_hi = min (n_lo + (long long) kD8ChunkSteps, (long long) q.nsteps);
+  const int nwords = int ((n_hi - n_lo + 63) >> 6);
+  for (int i = threadIdx.x; i < nwords; i += 128) bm[i] = q.trig[(n_lo >> 6) + i];
+  __syncthreads ();
+  const int r = threadIdx.x;
+  if (r >= kD8Net) return;
+  long long pos = r, len = n_hi - n_lo;
+  int exit_off = 0;
+  for (;;) {
+    if (pos >= len) { exit_off = int (min (pos - len, (long long) (kD8Net - 1))); break; }
+    const long long s = first_trig (bm, nwords, pos);
+    if (s < 0) { exit_off = 0; break; }
+    pos = s + kD8Net;
+  }
+  q.table[size_t (c) * 128 + r] = uint8_t (exit_off);
+}
+
+// One thread: what happens before step 0 (a window carried in, triggers among the last steps of the previous
+// call, ref: :493-496 re-scans them), then the entry offset of every chunk.
+// pre[0] = count, pre[1..2] = window starts (< 0) found there.
+__global__ void d8_chain_resolve_kernel (const D8Params q, u64 trig_tail, long long search0, long long *pre)
+{
+  if (threadIdx.x || blockIdx.x) return;
+  long long pos = search0;
+  int npre = 0;
+  if (q.pending < 0) { pre[1 + npre++] = q.pending; pos = q.pending + kD8Net; }
+  while (pos < 0) {                                        // steps -64 .. -1 of the previous call
+    const int b = int (pos + 64);
+    const u64 word = b >= 0 ? trig_tail & (~0ull << b) : trig_tail;
+    if (!word) { pos = 0; break; }
+    const long long s = (long long) __builtin_ctzll (word) - 64;
+    pre[1 + npre++] = s;
+    pos = s + kD8Net;
+  }
+  pre[0] = npre;
+  uint32_t e = uint32_t (min (pos, (long long) (kD8Net - 1)));
+  q.entry[0] = uint8_t (e);
+  for (uint32_t c = 0; c < q.nchunks; c++) { e = q.table[size_t (c) * 128 + e]; q.entry[c + 1] = uint8_t (e); }
+}
+
+// per chunk: the window openings themselves; the last one may still be open when the stream ends
+__global__ __launch_bounds__ (64)
+void d8_chain_walk_kernel (const D8Params q, const long long *pre, long long *pending_out)
+{
+  __shared__ u64 bm[kD8ChunkSteps / 64];
+  const uint32_t c = blockIdx.x;
+  const long long n_lo = (long long) c * kD8ChunkSteps, n_hi = min (n_lo + (long long) kD8ChunkSteps, (long long) q.nsteps);
+  const int nwords = int ((n_hi - n_lo + 63) >> 6);
+  for (int i = threadIdx.x; i < nwords; i += 64) bm[i] = q.trig[(n_lo >> 6) + i];
+  __syncthreads ();
+  if (threadIdx.x) return;
+  int64_t *ws = q.win_start + size_t (c) * kD8WinCap;
+  uint32_t n = 0;
+  if (c == 0)
+    for (int k = 0; k < int (pre[0]); k++) {
+      const long long s = pre[1 + k];
+      if (s + kD8Win <= (long long) q.nsteps) ws[n++] = s; else *pending_out = s - (long long) q.nsteps;
+    }
+  long long pos = q.entry[c], len = n_hi - n_lo;
+  while (pos < len) {
+    const long long s = first_trig (bm, nwords, pos);
+    if (s < 0) break;
+    if (n_lo + s + kD8Win <= (long long) q.nsteps) { if (n < uint32_t (kD8WinCap)) ws[n] = n_lo + s; n++; }
+    else *pending_out = n_lo + s - (long long) q.nsteps;
+    pos = s + kD8Net;
+  }
+  q.win_count[c] = n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one completed window per wave (ref: :331-420): match curve, peak, the two search strings, 32 candidates
+// ---------------------------------------------------------------------------------------------
+template <int CONV>
+__global__ __launch_bounds__ (64 * kW8)
+void d8_window_kernel (const D8Params q)
+{
+  __shared__ WinLds lds[kW8];
+  __shared__ uint32_t crc_tab[256];
+  const int lane = lane_id ();
+  const int wv = threadIdx.x >> 6;
+  WinLds &w = lds[wv];
+  crc_tab[threadIdx.x & 255] = q.sp.crc_table[threadIdx.x & 255];
+  __syncthreads ();
+  const uint32_t chunk = blockIdx.x;
+  const uint32_t nwin = min (q.win_count[chunk], uint32_t (kD8WinCap));
+  for (int i = lane; i < 256; i += 64) w.lut[i] = q.sp.lut256 ? q.sp.lut256[i] : uint16_t (0);
+
+  for (uint32_t k = blockIdx.y * kW8 + wv; k < nwin; k += gridDim.y * kW8) {
+    const long long s = q.win_start[size_t (chunk) * kD8WinCap + k];
+    const long long gbase = 8 * (s - 4);                                     // dw[0] = D'[gbase]
+    const long long xlo = gbase - kD8LookAhead;
+    const long long slo = xlo - (long long) (CONV == kConvMagU16 ? 0u : q.sp.ov);
+    const long long a_lo = (slo >= 0 ? slo : slo - 15) / 16 * 16;
+    const long long x0 = xlo - (slo - a_lo);
+    __builtin_amdgcn_s_waitcnt (0xc07f);
+    __builtin_amdgcn_wave_barrier ();
+    stage_tile<CONV, kWinTile> (w.tile, w.lut, q.sp, a_lo, lane);
+    __builtin_amdgcn_s_waitcnt (0xc07f);
+    __builtin_amdgcn_wave_barrier ();
+
+    // the block whose demod_8000 call completes the window, and how far that call's buffer is filled (ref: :203-215)
+    const uint64_t B = q.sp.block_samples;
+    const uint64_t done = uint64_t (8 * (s + kD8Win - 1));                   // sptr of the last recorded step
+    const uint64_t blkc = q.bshift >= 63 ? 0 : done >> q.bshift;
+    const uint64_t mlen_c = min (B, q.T - blkc * B);
+    const long long fill_g = (long long) (blkc * B + mlen_c) + kD8LookAhead;
+    for (int idx = lane; idx < kWinRows * 8; idx += 64) {
+      const long long g = gbase + idx;
+      int d;
+      if (g < fill_g) d = dprime_tile (q, w.tile, x0, g);
+      else {
+        // beyond what this call wrote: the buffer still holds what the previous call put at that index, or the
+        // zeros it was allocated with (ref: :106-123, 208-215, 509)
+        d = 0;
+        const uint64_t jj = uint64_t (g - kD8LookAhead) - blkc * B;
+        if (blkc >= 1 && jj < B && q.bshift < 63) {
+          const long long xp = (long long) ((blkc - 1) * B + jj);
+          const uint16_t va = mag_of_V<CONV> (q.sp.iq, q.sp.nsamples, q.sp.halo, q.sp.ov, q.sp.block_samples, q.sp.lut256, xp);
+          d = va;
+          if (jj + 4 < B) d -= mag_of_V<CONV> (q.sp.iq, q.sp.nsamples, q.sp.halo, q.sp.ov, q.sp.block_samples, q.sp.lut256, xp + 4);
+        }
+      }
+      w.dw[idx] = d;
+    }
+    __builtin_amdgcn_s_waitcnt (0xc07f);
+    __builtin_amdgcn_wave_barrier ();
+
+    // phase sums of steps s .. s+167: rows m = s+1 .. s+223 <-> dw rows 5 .. 227
+    for (int idx = lane; idx < 224 * 8; idx += 64) {
+      const int d = idx < 223 * 8 ? w.dw[5 * 8 + idx] : 0;
+      w.c[idx] = uint32_t (d < 0 ? -d : d);
+    }
+    __builtin_amdgcn_s_waitcnt (0xc07f);
+    __builtin_amdgcn_wave_barrier ();
+    column_prefix (w.c, w.tot, 28, lane);
+
+    // best phase of every step (first maximum wins, ref: :305-307); the match follows the opening step's phase
+    int start_phase = 0;
+    for (int it = 0; it < 3; it++) {
+      const int t = it * 64 + lane;
+      int best = 0; uint32_t mxv = 0, ph[8];
+      if (t < kD8Win) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) { ph[i] = w.c[(t + 56) * 8 + i] - w.c[t * 8 + i]; if (ph[i] > mxv) { mxv = ph[i]; best = i; } }
+        w.par[t] = uint8_t (best);
+      }
+      if (it == 0) start_phase = __builtin_amdgcn_readfirstlane (best);
+      if (t < kD8Win) w.match[t] = int (w.c[(t + 56) * 8 + start_phase] - w.c[t * 8 + start_phase]);
+    }
+    __builtin_amdgcn_s_waitcnt (0xc07f);
+    __builtin_amdgcn_wave_barrier ();
+
+    // pick_peak (ref: :529-553): the last index holding the maximum
+    uint32_t k0 = 0, k1 = 0;
+    for (int i = lane; i < kD8Win - kShortBits; i += 64) {
+      const uint32_t a = uint32_t (w.match[i]), b = a + uint32_t (w.match[i + kShortBits]);
+      k0 = max (k0, a * 128u + uint32_t (i));
+      k1 = max (k1, b * 128u + uint32_t (i));
+    }
+    for (int d = 32; d >= 1; d >>= 1) { k0 = max (k0, uint32_t (__shfl_xor (int (k0), d, 64))); k1 = max (k1, uint32_t (__shfl_xor (int (k1), d, 64))); }
+    const int peak_short = int (k0 & 127), peak_long = int (k1 & 127);
+    const long long win_start = 8 * (s + 1);
+    const long long g_short = win_start + w.par[peak_short] + (peak_short - 4) * 8;
+    const long long g_long = win_start + w.par[peak_long] + (peak_long - 4) * 8;
+
+    // the two bit strings (ref: :352-364): bit = !(sum of three differences < 0), first bit first
+    u64 S[2][2];
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+      const long long g = pass ? g_long : g_short;
+      const int nbits = pass ? 128 : 72;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int kb = h * 64 + lane;
+        bool bit = false;
+        if (kb < nbits) {
+          const int o = int (g + 8 * kb - gbase);
+          bit = (w.dw[o - 1] + w.dw[o] + w.dw[o + 1]) >= 0;
+        }
+        S[pass][h] = __ballot (bit);
+      }
+    }
+
+    // 32 candidates: lane = pass * 16 + shift (ref: :368-379)
+    bool keep = false;
+    uint4 lo4 = { 0, 0, 0, 0 }, hi4 = { 0, 0, 0, 0 };
+    if (lane < kD8Cand) {
+      const int pass = lane >> 4, sh = lane & 15;
+      const u64 A = S[pass][0], Bw = S[pass][1];
+      const u64 x0b = sh ? (A >> sh) | (Bw << (64 - sh)) : A;
+      const u64 x1b = Bw >> sh;
+      uint32_t W[4];
+      W[0] = rev_in_bytes (uint32_t (x0b)); W[1] = rev_in_bytes (uint32_t (x0b >> 32));
+      W[2] = rev_in_bytes (uint32_t (x1b)); W[3] = rev_in_bytes (uint32_t (x1b >> 32)) & 0xFFFF;
+      if (!pass) { W[1] &= 0x00FFFFFF; W[2] = 0; W[3] = 0; }                 // memcpy (best_msg, msg, 7) (ref: :374)
+      const int valid_bits = pass ? kLongBits : kShortBits;
+      const int df = int ((W[0] & 0xFF) >> 3);
+      const int bits = len_by_type8 (df);
+      keep = valid_bits >= bits;                                              // ref: src/dump1090.c:3286-3292
+      if (keep) keep = bits == kLongBits ? (W[0] | W[1] | W[2] | W[3]) != 0 : (W[0] | (W[1] & 0x00FFFFFF)) != 0;
+      int cls = kClsAP, nerr = 0, b0 = 0, b1 = 0;
+      uint32_t crc = 0;
+      if (keep) {
+        crc = crc_words (crc_tab, W, bits / 8);
+        const bool es = df == 17 || df == 18, acq = df == 11;
+        if (es || acq) {
+          cls = acq ? kClsDF11 : kClsES;
+          const uint32_t key = acq ? (crc & 0xFFFF80u) : crc;
+          if (key) {
+            const bool shortt = bits == kShortBits;
+            const ErrEntry *tab = shortt ? q.sp.short_tab : q.sp.long_tab;
+            const int tn = shortt ? q.sp.short_n : q.sp.long_n;
+            const uint32_t h = (key ^ (key >> 12)) & 0xFFFF;
+            const uint32_t *bloom = shortt ? q.sp.bloom_short : q.sp.bloom_long;
+            int hit = -1;
+            if (tn > 0 && ((bloom[h >> 5] >> (h & 31)) & 1)) hit = table_lookup8 (tab, tn, key);
+            if (hit < 0) keep = false;
+            else {
+              const ErrEntry te = tab[hit];
+              if (acq && te.nerr > 1) keep = false;
+              else { nerr = te.nerr; b0 = te.bit0; b1 = te.bit1; }
+            }
+          }
+        } else if (df == 0 || df == 4 || df == 5 || df == 16 || df == 24) cls = kClsAP;
+        else if (df == 20 || df == 21) cls = kClsAP2;
+        else keep = false;
+      }
+      lo4.x = uint32_t (lane) << 16 | (uint32_t (df) << 24);                  // Record.phase = candidate index
+      lo4.y = uint32_t (cls) | (uint32_t (uint8_t (nerr)) << 8) | (uint32_t (uint8_t (b0)) << 16) | (uint32_t (uint8_t (b1)) << 24);
+      lo4.z = crc; lo4.w = W[0];
+      hi4.x = W[1]; hi4.y = W[2]; hi4.z = W[3] & 0xFFFF; hi4.w = 0;
+    }
+    const u64 km = __ballot (keep);
+    const size_t slot = size_t (chunk) * kD8WinCap + k;
+    if (keep) {
+      uint4 *dst = reinterpret_cast<uint4 *> (q.records + slot * kD8Cand + __popcll (km & ((1ull << lane) - 1)));
+      dst[0] = lo4; dst[1] = hi4;
+    }
+    if (lane == 0) {
+      D8Window h;
+      h.s = s; h.g_short = g_short; h.g_long = g_long; h.nrec = uint32_t (__popcll (km)); h.pad = 0;
+      q.windows[slot] = h;
+    }
+  }
+}
+
+// the last kD8Overlap differences of the stream, for the next call (ref: :509)
+template <int CONV>
+__global__ __launch_bounds__ (256)
+void d8_tail_kernel (const D8Params q, int32_t *dnext)
+{
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= kD8Overlap) return;
+  // next call's D'[g'] for g' in [-1384, 544) is this call's D'[g' + T]
+  const long long g = (long long) q.T + idx - kD8LookBack;
+  int d;
+  if (g < kD8LookAhead) d = (q.dprev && g >= -kD8LookBack) ? q.dprev[g + kD8LookBack] : 0;
+  else {
+    const uint64_t P = uint64_t (g - kD8LookAhead);
+    const uint64_t B = q.sp.block_samples;
+    const uint64_t blk = q.bshift >= 63 ? 0 : P >> q.bshift;
+    const uint64_t j = P - blk * B, mlen = min (B, q.T - blk * B);
+    d = mag_of_V<CONV> (q.sp.iq, CONV == kConvMagU16 ? q.sp.navail : q.sp.nsamples, q.sp.halo, q.sp.ov, q.sp.block_samples, q.sp.lut256, (long long) P);
+    if (j + 4 < mlen)
+      d -= mag_of_V<CONV> (q.sp.iq, CONV == kConvMagU16 ? q.sp.navail : q.sp.nsamples, q.sp.halo, q.sp.ov, q.sp.block_samples, q.sp.lut256, (long long) P + 4);
+  }
+  dnext[idx] = d;
+}
+
+// index just behind the last step that needs the running average (0 = none)
+__global__ __launch_bounds__ (256)
+void d8_last_amb_kernel (const uint64_t *amb, uint64_t nwords, unsigned long long *limit)
+{
+  const uint64_t i = uint64_t (blockIdx.x) * 256 + threadIdx.x;
+  if (i >= nwords) return;
+  const uint64_t wv = amb[i];
+  if (wv) atomicMax (limit, (unsigned long long) (i * 64 + 64 - __builtin_clzll (wv)));
+}
+
+hipError_t launch_d8_last_amb (const uint64_t *amb, uint64_t nwords, unsigned long long *limit, hipStream_t stream)
+{
+  if (nwords) hipLaunchKernelGGL (d8_last_amb_kernel, dim3 ((unsigned) ((nwords + 255) / 256)), dim3 (256), 0, stream, amb, nwords, limit);
+  return hipGetLastError ();
+}
+
+// ---- compaction of the per-window slots into two dense arrays, window order kept ----
+__global__ __launch_bounds__ (256)
+void d8_count_kernel (const D8Params q, uint32_t *chunk_rec)
+{
+  __shared__ uint32_t part[256];
+  const uint32_t c = blockIdx.x, nwin = min (q.win_count[c], uint32_t (kD8WinCap));
+  uint32_t sum = 0;
+  for (uint32_t k = threadIdx.x; k < nwin; k += 256) sum += q.windows[size_t (c) * kD8WinCap + k].nrec;
+  part[threadIdx.x] = sum;
+  __syncthreads ();
+  for (int d = 128; d >= 1; d >>= 1) { if (threadIdx.x < (unsigned) d) part[threadIdx.x] += part[threadIdx.x + d]; __syncthreads (); }
+  if (threadIdx.x == 0) chunk_rec[c] = part[0];
+}
+
+__global__ __launch_bounds__ (256)
+void d8_gather_kernel (const D8Params q, const uint64_t *win_off, const uint64_t *rec_off, D8Window *win_out, Record *rec_out)
+{
+  __shared__ uint32_t pre[kD8WinCap + 1];
+  const uint32_t c = blockIdx.x, nwin = min (q.win_count[c], uint32_t (kD8WinCap));
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (uint32_t k = 0; k < nwin; k++) { pre[k] = run; run += q.windows[size_t (c) * kD8WinCap + k].nrec; }
+  }
+  __syncthreads ();
+  for (uint32_t k = threadIdx.x; k < nwin; k += 256) {
+    D8Window h = q.windows[size_t (c) * kD8WinCap + k];
+    const uint64_t ro = rec_off[c] + pre[k];
+    const uint4 *src = reinterpret_cast<const uint4 *> (q.records + (size_t (c) * kD8WinCap + k) * kD8Cand);
+    uint4 *dst = reinterpret_cast<uint4 *> (rec_out + ro);
+    for (uint32_t r = 0; r < 2 * h.nrec; r++) dst[r] = src[r];
+    h.pad = uint32_t (ro);
+    win_out[win_off[c] + k] = h;
+  }
+}
+
+hipError_t launch_d8_count (const D8Params &q, uint32_t *chunk_rec, hipStream_t stream)
+{
+  if (q.nchunks) hipLaunchKernelGGL (d8_count_kernel, dim3 (q.nchunks), dim3 (256), 0, stream, q, chunk_rec);
+  return hipGetLastError ();
+}
+
+hipError_t launch_d8_gather (const D8Params &q, const uint64_t *win_off, const uint64_t *rec_off, D8Window *win_out,
+                             Record *rec_out, hipStream_t stream)
+{
+  if (q.nchunks) hipLaunchKernelGGL (d8_gather_kernel, dim3 (q.nchunks), dim3 (256), 0, stream, q, win_off, rec_off, win_out, rec_out);
+  return hipGetLastError ();
+}
+
+hipError_t upload_constants_8000 (const uint32_t *single_bit, const float *uc8_float)
+{
+  return upload_constants_tu (single_bit, uc8_float);
+}
+
+#define D8_DISPATCH(KERNEL, GRID, BLOCK, ...)                                                                      \
+  switch (q.sp.conv) {                                                                                              \
+    case kConvUc8Lut: case kConvUc8LutPower: hipLaunchKernelGGL (KERNEL<kConvUc8Lut>, GRID, BLOCK, 0, stream, __VA_ARGS__); break;   \
+    case kConvUc8Generic:     hipLaunchKernelGGL (KERNEL<kConvUc8Generic>, GRID, BLOCK, 0, stream, __VA_ARGS__); break;     \
+    case kConvSc16Int:        hipLaunchKernelGGL (KERNEL<kConvSc16Int>, GRID, BLOCK, 0, stream, __VA_ARGS__); break;        \
+    case kConvSc16Generic:    hipLaunchKernelGGL (KERNEL<kConvSc16Generic>, GRID, BLOCK, 0, stream, __VA_ARGS__); break;    \
+    case kConvSc16Q11Generic: hipLaunchKernelGGL (KERNEL<kConvSc16Q11Generic>, GRID, BLOCK, 0, stream, __VA_ARGS__); break; \
+    case kConvMagU16:         hipLaunchKernelGGL (KERNEL<kConvMagU16>, GRID, BLOCK, 0, stream, __VA_ARGS__); break;         \
+    default: return hipErrorInvalidValue;                                                                           \
+  }
+
+hipError_t launch_d8_trig (const D8Params &q, hipStream_t stream)
+{
+  if (q.nsteps == 0) return hipSuccess;
+  const uint64_t nstrips = (q.nsteps + kD8StripSteps - 1) / kD8StripSteps;
+  const dim3 grid ((unsigned) ((nstrips + kW8 - 1) / kW8)), block (64 * kW8);
+  D8_DISPATCH (d8_trig_kernel, grid, block, q);
+  return hipGetLastError ();
+}
+
+hipError_t launch_d8_acc (const D8Params &q, uint64_t limit, int32_t *acc_out, hipStream_t stream)
+{
+  hipLaunchKernelGGL (d8_acc_kernel, dim3 (1), dim3 (64), 0, stream, q, limit, acc_out);
+  return hipGetLastError ();
+}
+
+hipError_t launch_d8_chain (const D8Params &q, unsigned long long trig_tail, long long search0, long long *pre,
+                            long long *pending_out, hipStream_t stream)
+{
+  if (q.nchunks) hipLaunchKernelGGL (d8_chain_table_kernel, dim3 (q.nchunks), dim3 (128), 0, stream, q);
+  hipLaunchKernelGGL (d8_chain_resolve_kernel, dim3 (1), dim3 (1), 0, stream, q, (u64) trig_tail, search0, pre);
+  if (q.nchunks) hipLaunchKernelGGL (d8_chain_walk_kernel, dim3 (q.nchunks), dim3 (64), 0, stream, q, pre, pending_out);
+  return hipGetLastError ();
+}
+
+hipError_t launch_d8_windows (const D8Params &q, hipStream_t stream)
+{
+  if (q.nchunks == 0) return hipSuccess;
+  const dim3 grid (q.nchunks, 16), block (64 * kW8);
+  D8_DISPATCH (d8_window_kernel, grid, block, q);
+  return hipGetLastError ();
+}
+
+hipError_t launch_d8_tail (const D8Params &q, int32_t *dnext, hipStream_t stream)
+{
+  const dim3 grid ((kD8Overlap + 255) / 256), block (256);
+  D8_DISPATCH (d8_tail_kernel, grid, block, q, dnext);
+  return hipGetLastError ();
+}
+
+}  // namespace modes

@@ -1,0 +1,72 @@
+"""GPU parity: the HIP engine behind the C ABI against the CPU oracle, 8 MS/s path (demod_8000, BASELINE.json
+configs[3]).  Bit-exact on every integer/byte field; sig_level within 1e-5 relative."""
+import numpy as np
+import pytest
+
+import dump1090_amd as da
+from dump1090_amd import synth
+from util import assert_same_messages, oracle_run
+
+pytestmark = pytest.mark.gpu
+FMT = {"uc8": da.INPUT_UC8, "sc16": da.INPUT_SC16, "sc16q11": da.INPUT_SC16Q11}
+STAT_KEYS = ("valid_preamble", "demodulated", "CRC_good", "CRC_bad", "CRC_single_bit_fix", "CRC_two_bits_fix",
+             "demod_rejected_unknown")
+
+
+def check(iq, fmt, min_msgs, **kw):
+    exp, est = oracle_run(iq, fmt, rate=8000000, **kw)
+    e = da.Engine(8000000, FMT[fmt], **kw)
+    e.run_host(iq)
+    got, gst = e.messages(), e.stats()
+    assert len(exp) >= min_msgs, len(exp)
+    assert_same_messages(got, exp)
+    for k in STAT_KEYS:
+        assert gst[k] == est[k], (k, gst[k], est[k])
+    return got
+
+
+@pytest.mark.parametrize("fix_bits", [0, 1, 2])
+def test_sc16_synthetic_matches_oracle(fix_bits):
+    iq, _ = synth.capture(4_000_000, 8.0e6, "sc16", seed=70 + fix_bits, frames_per_sec=2000, bitflip1=0.2, bitflip2=0.05,
+                          ap_fraction=0.25)
+    check(iq, "sc16", 500, fix_bits=fix_bits)
+
+
+def test_quiet_input_needs_the_running_average():
+    """Noise of a few LSB keeps max(phase) in the band where the trigger depends on phase_av."""
+    iq, _ = synth.capture(1_500_000, 8.0e6, "sc16", seed=81, frames_per_sec=1500, noise_sigma=0.0003,
+                          min_amp_db=-50, max_amp_db=-30, ap_fraction=0.2)
+    check(iq, "sc16", 100)
+
+
+def test_silence_then_signal():
+    iq, _ = synth.capture(1_200_000, 8.0e6, "sc16", seed=82, frames_per_sec=2000)
+    iq[: 2 * 300_000] = 0
+    iq[2 * 700_000: 2 * 800_000] = 0
+    check(iq, "sc16", 50)
+
+
+def test_sc16_generic_power_path():
+    iq, _ = synth.capture(1_000_000, 8.0e6, "sc16", seed=83, frames_per_sec=2000)
+    check(iq, "sc16", 100, compute_power=True)
+
+
+@pytest.mark.parametrize("nsamples", [0, 7, 8, 543, 544, 1400, 2047, 65536, 65537, 65536 * 2 + 4321])
+def test_ragged_lengths(nsamples):
+    iq, _ = synth.capture(max(nsamples, 1), 8.0e6, "sc16", seed=84, frames_per_sec=4000, min_amp_db=-12)
+    iq = iq[: 2 * nsamples]
+    check(iq, "sc16", 0)
+
+
+def test_messages_straddling_block_boundaries():
+    rng = np.random.default_rng(27)
+    offs = (-1400, -1100, -960, -900, -700, -480, -300, -100, -8, 0, 30)
+    n = 65536 * (len(offs) + 1) + 3000
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.005
+    for b, d in enumerate(offs, start=1):
+        msg = synth.make_df17(0x4840D6 + b, bytes(rng.integers(0, 256, 7, dtype=np.uint8)))
+        env = synth.envelope(msg, 8.0e6, rng.random())
+        p = b * 65536 + d
+        x[p:p + len(env)] += 0.3 * np.exp(2j * np.pi * rng.random()) * env
+    iq = synth.quantise(x, "sc16")
+    check(iq, "sc16", len(offs) - 3)
