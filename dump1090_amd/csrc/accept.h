@@ -80,10 +80,14 @@ struct Pass8000Stats {
   uint64_t valid_preamble = 0, demodulated = 0, CRC_good = 0, CRC_bad = 0, CRC_single_bit_fix = 0, CRC_two_bits_fix = 0,
            rejected_unknown = 0;
 };
-// rssi_pos / rssi_len / rssi_msg: scan position, length and message index of every signal-level sum still to be formed
+struct Pass8000Hooks {
+  std::function<int (const Record &r, int valid_bits)> score;            // modeS_message_score
+  // decode_mode_S_message with mm.timestamp_msg already set to `timestamp`; fills `out` on success
+  std::function<int (const Record &r, uint64_t timestamp, modes_message *out)> decode;
+  // modeS_user_message; m_start >= 0: the signal level is the mean square of `slen` magnitudes from there (block-relative)
+  std::function<void (modes_message &m, const Record &r, uint64_t blkc, int m_start, int slen)> emit;
+};
 void accept_pass_8000 (const D8Window *win, size_t nwin, const Record *rec, uint32_t block_samples, int bshift, uint64_t T,
-                       uint32_t ov, uint64_t first_sample, uint32_t sample_rate, IcaoCache &cache, Pass8000Stats &st,
-                       std::vector<modes_message> &out, std::vector<uint64_t> &rssi_pos, std::vector<uint32_t> &rssi_len,
-                       std::vector<uint32_t> &rssi_msg);
+                       uint32_t ov, uint64_t first_sample, uint32_t sample_rate, const Pass8000Hooks &hooks, Pass8000Stats &st);
 
 }  // namespace modes

@@ -56,6 +56,19 @@ struct DropIn {
   std::vector<modes_message> queue;
   uint32_t block_counter = 0;
   bool d8_allocated = false;
+  // demod_8000: what the reference keeps in file-static variables between calls (ref: src/demod-8000.c:80-89)
+  struct D8 {
+    int32_t *dprev = nullptr, *dnext = nullptr;     // the last 1928 differences (d8m_dbuf's overlap)
+    int32_t acc = 0;                                // d8m_phase_av_acc
+    long long pending = 1;                          // step (< 0) at which the window still open was opened; 1 = none
+    unsigned long long trig_tail = 0;               // trigger decisions of the last 64 steps (re-scanned after a window)
+    // scratch
+    uint64_t *trig = nullptr, *amb = nullptr, *off = nullptr; size_t words = 0;
+    uint32_t *p0 = nullptr, *mx = nullptr; size_t steps = 0;
+    uint8_t *table = nullptr, *entry = nullptr; int64_t *win_start = nullptr; uint32_t *win_count = nullptr, *chunk_rec = nullptr;
+    D8Window *windows = nullptr, *win_packed = nullptr; Record *records = nullptr, *rec_packed = nullptr; size_t chunks = 0;
+    long long *small = nullptr;
+  } d8;
 };
 
 DropIn g;
@@ -290,7 +303,11 @@ extern "C" {
 int modes_hip_bind (const modes_hip_host *host)
 {
   std::lock_guard<std::mutex> lk (g.mu);
-  if (!host) { g.bound = false; memset (&g.host, 0, sizeof g.host); return MODES_OK; }
+  if (!host) {      // back to the built-in rules, with the state a fresh process would have
+    g.bound = false; memset (&g.host, 0, sizeof g.host);
+    g.cache.clear (); g.queue.clear (); g.block_counter = 0;
+    return MODES_OK;
+  }
   if (host->mm_size && (host->off_sig_level + sizeof (double) > host->mm_size || host->off_timestamp_msg + 8 > host->mm_size))
     return set_error (MODES_E_ARG, "modes_hip_bind: offsets outside modeS_message");
   g.host = *host;
@@ -440,12 +457,6 @@ void demod_2400 (const mag_buf *mag)
   }
 }
 
-static void not_built (const char *name)
-{
-  set_error (MODES_E_ARG, "%s: this demodulator has no HIP path yet", name);
-  fprintf (stderr, "modes_hip: %s\n", modes_last_error ());
-}
-
 // ref: src/demod-2000.c:612-1027.  The kernel slices every valid preamble (and its retries); the loop's order,
 // the callbacks and the skip-ahead happen here.
 void demod_2000 (const mag_buf *mag)
@@ -540,9 +551,198 @@ void demod_2400_AC (const mag_buf *mag)
     }
   }
 }
-void demod_8000 (const mag_buf *) { not_built ("demod_8000"); }
-int  demod_8000_alloc (void) { g.d8_allocated = true; return 1; }
-void demod_8000_free (void) { g.d8_allocated = false; }
+// ref: src/demod-8000.c:106-123
+int demod_8000_alloc (void)
+{
+  std::lock_guard<std::mutex> lk (g.mu);
+  if (!ensure_ready ()) return 0;
+  auto &s = g.d8;
+  if (!s.dprev) {
+    if (hipMalloc (reinterpret_cast<void **> (&s.dprev), kD8Overlap * sizeof (int32_t)) != hipSuccess) return 0;
+    if (hipMalloc (reinterpret_cast<void **> (&s.dnext), kD8Overlap * sizeof (int32_t)) != hipSuccess) return 0;
+    if (hipMalloc (reinterpret_cast<void **> (&s.small), 16 * sizeof (long long)) != hipSuccess) return 0;
+  }
+  if (hipMemset (s.dprev, 0, kD8Overlap * sizeof (int32_t)) != hipSuccess) return 0;        // calloc
+  s.acc = 0; s.pending = 1; s.trig_tail = 0;
+  g.d8_allocated = true;
+  return 1;
+}
+
+void demod_8000_free (void)
+{
+  std::lock_guard<std::mutex> lk (g.mu);
+  g.d8_allocated = false;
+}
+
+static bool d8_grow (size_t nsteps, uint32_t nchunks)
+{
+  auto &s = g.d8;
+  const size_t words = nsteps / 64 + 64;
+  if (words > s.words) {
+    for (void *p : { (void *) s.trig, (void *) s.amb }) if (p) (void) hipFree (p);
+    s.trig = s.amb = nullptr; s.words = 0;
+    HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.trig), words * sizeof (uint64_t)));
+    HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.amb), words * sizeof (uint64_t)));
+    s.words = words;
+  }
+  if (nsteps > s.steps) {
+    for (void *p : { (void *) s.p0, (void *) s.mx }) if (p) (void) hipFree (p);
+    s.p0 = s.mx = nullptr; s.steps = 0;
+    HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.p0), (nsteps + 64) * sizeof (uint32_t)));
+    HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.mx), (nsteps + 64) * sizeof (uint32_t)));
+    s.steps = nsteps;
+  }
+  if (nchunks > s.chunks) {
+    for (void *p : { (void *) s.table, (void *) s.entry, (void *) s.win_start, (void *) s.win_count, (void *) s.chunk_rec,
+                     (void *) s.windows, (void *) s.win_packed, (void *) s.records, (void *) s.rec_packed, (void *) s.off })
+      if (p) (void) hipFree (p);
+    s.chunks = 0;
+    const size_t nw = size_t (nchunks) * kD8WinCap;
+    HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.table), size_t (nchunks) * 128));
+    HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.entry), nchunks + 1));
+    HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.win_start), nw * sizeof (int64_t)));
+    HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.win_count), nchunks * sizeof (uint32_t)));
+    HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.chunk_rec), nchunks * sizeof (uint32_t)));
+    HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.windows), nw * sizeof (D8Window)));
+    HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.win_packed), nw * sizeof (D8Window)));
+    HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.records), nw * kD8Cand * sizeof (Record)));
+    HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.rec_packed), nw * kD8Cand * sizeof (Record)));
+    HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.off), (2 * size_t (nchunks) + 2) * sizeof (uint64_t)));
+    s.chunks = nchunks;
+  }
+  return true;
+}
+
+static bool demod_8000_locked (const mag_buf *mag, uint32_t block)
+{
+  auto &s = g.d8;
+  if (!g.d8_allocated || !s.dprev) {
+    set_error (MODES_E_ARG, "demod_8000 called without demod_8000_alloc()");
+    fprintf (stderr, "modes_hip: %s\n", modes_last_error ());
+    return false;
+  }
+  if (!ensure_ready () || !ensure_tables ()) return false;
+  HIP_OK (hipSetDevice (g.device));
+  const uint64_t T = uint64_t (mag->valid_length - mag->overlap) & ~7ull;                   // ref: :203
+  const uint64_t nsteps = T / 8;
+  if (!nsteps) return true;
+  const uint32_t nchunks = uint32_t ((nsteps + kD8ChunkSteps - 1) / kD8ChunkSteps);
+  if (!grow (g.d_mag, g.mag_cap, size_t (mag->valid_length) + 64) || !d8_grow (nsteps, nchunks)) return false;
+  HIP_OK (hipMemcpyAsync (g.d_mag, mag->data, size_t (mag->valid_length) * 2, hipMemcpyHostToDevice, nullptr));
+
+  D8Params q;
+  memset (&q, 0, sizeof q);
+  q.sp.iq = reinterpret_cast<const uint8_t *> (g.d_mag); q.sp.nsamples = T; q.sp.navail = mag->valid_length;
+  q.sp.ov = mag->overlap; q.sp.block_samples = uint32_t (T); q.sp.conv = kConvMagU16;
+  q.sp.short_tab = g.d_short; q.sp.short_n = g.short_n; q.sp.long_tab = g.d_long; q.sp.long_n = g.long_n;
+  q.sp.bloom_short = g.d_bloom_short; q.sp.bloom_long = g.d_bloom_long; q.sp.lut256 = g.d_lut; q.sp.crc_table = g.d_crc_table;
+  q.T = T; q.nsteps = nsteps; q.bshift = 63; q.dprev = s.dprev; q.acc0 = s.acc; q.pending = s.pending; q.nchunks = nchunks;
+  q.trig = s.trig; q.amb = s.amb; q.p0 = s.p0; q.mx = s.mx; q.write_arrays = 1;
+  q.table = s.table; q.entry = s.entry; q.win_start = s.win_start; q.win_count = s.win_count; q.windows = s.windows; q.records = s.records;
+  long long *d_pre = s.small, *d_pending = s.small + 4;
+  q.amb_count = reinterpret_cast<uint32_t *> (s.small + 5);
+  int32_t *d_acc = reinterpret_cast<int32_t *> (s.small + 6);
+  const long long init[8] = { 0, 0, 0, 0, 1, 0, 0, 0 };
+  HIP_OK (hipMemcpyAsync (d_pre, init, sizeof init, hipMemcpyHostToDevice, nullptr));
+  const size_t words = size_t (nsteps / 64 + 64);
+  HIP_OK (hipMemsetAsync (q.trig, 0, words * sizeof (uint64_t), nullptr));
+  HIP_OK (hipMemsetAsync (q.amb, 0, words * sizeof (uint64_t), nullptr));
+  HIP_OK (launch_d8_trig (q, nullptr));
+  HIP_OK (launch_d8_acc (q, nsteps, d_acc, nullptr));           // the running average is carried to the next call: always formed
+  HIP_OK (launch_d8_chain (q, s.trig_tail, 0ll, d_pre, d_pending, nullptr));
+  HIP_OK (launch_d8_windows (q, nullptr));
+  HIP_OK (launch_d8_tail (q, s.dnext, nullptr));
+  HIP_OK (launch_d8_count (q, s.chunk_rec, nullptr));
+  std::vector<uint32_t> wc (nchunks), rcnt (nchunks);
+  std::vector<uint64_t> trig (words);
+  long long small[8];
+  HIP_OK (hipMemcpyAsync (wc.data (), s.win_count, nchunks * sizeof (uint32_t), hipMemcpyDeviceToHost, nullptr));
+  HIP_OK (hipMemcpyAsync (rcnt.data (), s.chunk_rec, nchunks * sizeof (uint32_t), hipMemcpyDeviceToHost, nullptr));
+  HIP_OK (hipMemcpyAsync (trig.data (), s.trig, words * sizeof (uint64_t), hipMemcpyDeviceToHost, nullptr));
+  HIP_OK (hipMemcpyAsync (small, s.small, sizeof small, hipMemcpyDeviceToHost, nullptr));
+  HIP_OK (hipStreamSynchronize (nullptr));
+
+  // state for the next call
+  std::swap (s.dprev, s.dnext);
+  memcpy (&s.acc, &small[6], sizeof (int32_t));
+  s.pending = small[4];
+  {
+    unsigned long long tail = 0;
+    for (int b = 0; b < 64; b++) {
+      const long long n = (long long) nsteps - 64 + b;           // step of bit b
+      bool bit;
+      if (n >= 0) bit = (trig[size_t (n) >> 6] >> (n & 63)) & 1;
+      else bit = (n + 64 >= 0) ? ((s.trig_tail >> (n + 64)) & 1) : false;   // still a step of the call before
+      if (bit) tail |= 1ull << b;
+    }
+    s.trig_tail = tail;
+  }
+
+  std::vector<uint64_t> off (2 * size_t (nchunks) + 2);
+  uint64_t nwin = 0, nrec = 0;
+  for (uint32_t c = 0; c < nchunks; c++) {
+    if (wc[c] > uint32_t (kD8WinCap)) { set_error (MODES_E_OVERFLOW, "demod_8000: window list overflow"); return false; }
+    off[c] = nwin; off[nchunks + 1 + c] = nrec; nwin += wc[c]; nrec += rcnt[c];
+  }
+  if (!nwin) return true;
+  HIP_OK (hipMemcpyAsync (s.off, off.data (), off.size () * sizeof (uint64_t), hipMemcpyHostToDevice, nullptr));
+  HIP_OK (launch_d8_gather (q, s.off, s.off + nchunks + 1, s.win_packed, s.rec_packed, nullptr));
+  std::vector<D8Window> wins (nwin);
+  std::vector<Record> recs (nrec + 1);
+  HIP_OK (hipMemcpyAsync (wins.data (), s.win_packed, nwin * sizeof (D8Window), hipMemcpyDeviceToHost, nullptr));
+  if (nrec) HIP_OK (hipMemcpyAsync (recs.data (), s.rec_packed, nrec * sizeof (Record), hipMemcpyDeviceToHost, nullptr));
+  HIP_OK (hipStreamSynchronize (nullptr));
+
+  const bool have_cb = g.bound && g.host.modeS_message_score && g.host.decode_mode_S_message && g.host.mm_size;
+  HostMm mm;
+  if (have_cb) mm.buf.assign (g.host.mm_size, 0);
+  const uint16_t *m = mag->data;
+  Pass8000Hooks hooks;
+  Pass8000Stats ps;
+  hooks.score = [&] (const Record &r, int valid_bits) {
+    return have_cb ? g.host.modeS_message_score (r.msg, valid_bits) : score_record (r, g.cache);
+  };
+  hooks.decode = [&] (const Record &r, uint64_t ts_rel, modes_message *out) {
+    if (!have_cb) return accept_record (r, g.cache, out);
+    const uint64_t ts = mag->sample_timestamp + ts_rel;                                        // ref: :421-422
+    const int64_t ms = g.host.receiveclock_ms_elapsed ? g.host.receiveclock_ms_elapsed (mag->sample_timestamp, ts)
+                                                      : int64_t ((ts - mag->sample_timestamp) / 12000);
+    mm.at<uint64_t> (g.host.off_timestamp_msg) = ts;
+    mm.at<uint64_t> (g.host.off_sys_timestamp_msg) = mag->sys_timestamp + uint64_t (ms);
+    const int rc = g.host.decode_mode_S_message (mm.buf.data (), r.msg);
+    out->error_bits = uint8_t (mm.at<int> (g.host.off_error_bits));
+    out->addr = mm.at<uint32_t> (g.host.off_addr);
+    return rc;
+  };
+  hooks.emit = [&] (modes_message &out, const Record &, uint64_t, int m_start, int slen) {
+    double sig = 0.0;
+    if (m_start >= 0) {                                                                          // ref: :469-484
+      uint64_t scaled = 0;
+      for (int k = 0; k < slen; k++) { const uint32_t v = m[m_start + k]; scaled += uint64_t (v * v); }
+      sig = (double (scaled) / 65535.0 / 65535.0) / slen;
+    }
+    if (have_cb) {
+      if (m_start >= 0) mm.at<double> (g.host.off_sig_level) = sig;
+      if (out.addr && g.host.modeS_user_message) g.host.modeS_user_message (mm.buf.data ());   // ref: :487
+    } else if (out.addr) {
+      out.timestamp += mag->sample_timestamp;
+      out.sig_level = sig;
+      out.block = block;
+      g.queue.push_back (out);
+    }
+  };
+  accept_pass_8000 (wins.data (), nwin, recs.data (), uint32_t (T), 63, T, mag->overlap, 0, 8000000, hooks, ps);
+  return true;
+}
+
+// ref: src/demod-8000.c:143-523
+void demod_8000 (const mag_buf *mag)
+{
+  std::lock_guard<std::mutex> lk (g.mu);
+  const uint32_t block = g.block_counter++;
+  if (!mag || !mag->data || mag->valid_length < mag->overlap) return;
+  (void) demod_8000_locked (mag, block);
+}
 
 size_t modes_hip_take_messages (modes_message *out, size_t max)
 {

@@ -274,7 +274,7 @@ void d8_chain_walk_kernel (const D8Params q, const long long *pre, long long *pe
     const long long s = first_trig (bm, nwords, pos);
     if (s < 0) break;
     if (n_lo + s + kD8Win <= (long long) q.nsteps) { if (n < uint32_t (kD8WinCap)) ws[n] = n_lo + s; n++; }
-    else *pending_out = n_lo + s - (long long) q.nsteps;
+    else { *pending_out = n_lo + s - (long long) q.nsteps; break; }   // the stream ends inside this window: nothing opens after it
     pos = s + kD8Net;
   }
   q.win_count[c] = n;

@@ -134,7 +134,8 @@ typedef struct modes_hip_host {
   int      device;                  /* HIP device ordinal   */
 } modes_hip_host;
 
-/* Returns 0, or a negative modes_status.  Passing NULL restores the built-in defaults. */
+/* Returns 0, or a negative modes_status.  Passing NULL restores the built-in defaults and clears the built-in
+ * state (ICAO cache, queued messages, block counter). */
 int modes_hip_bind (const modes_hip_host *host);
 
 /* ===================================================================================== */

@@ -203,3 +203,76 @@ def test_demod_2000_with_host_callbacks_and_phase_enhance():
     for g, x in zip(got, exp):
         n = int(x["msg_bits"]) // 8
         assert bytes(g["msg"][:n]) == bytes(x["msg"][:n])
+
+
+def _elapsed(a, b):
+    """receiveclock_ms_elapsed (ref: src/misc.c:1259-1262): signed difference, C division."""
+    d = (b - a) & (2 ** 64 - 1)
+    d = d - 2 ** 64 if d >= 2 ** 63 else d
+    return (abs(d) // 12000) * (1 if d >= 0 else -1)
+
+
+def _run_blocks_8000(L, iq):
+    assert L.demod_8000_alloc() != 0
+    for data, ov, ts in blocks_of(iq, "sc16", rate=8000000):
+        mb = da.make_mag_buf(data, ov, sample_timestamp=ts)
+        L.demod_8000(C.byref(mb))
+    L.demod_8000_free()
+
+
+@pytest.mark.parametrize("quiet", [False, True])
+def test_demod_8000_per_block_builtin_rules(quiet):
+    """demod_8000 keeps its sliding sums, running average, open window and 1928 differences between calls."""
+    kw = dict(noise_sigma=0.0003, min_amp_db=-50, max_amp_db=-30) if quiet else {}
+    iq, _ = synth.capture(65536 * 6 + 4321, 8.0e6, "sc16", seed=35, frames_per_sec=2500, bitflip1=0.2, ap_fraction=0.3, **kw)
+    o = orc.Oracle(8000000, fix_bits=1)
+    o.run_stream(iq, orc.INPUT_SC16, 8000)
+    exp = o.messages()
+    L = da.lib()
+    L.modes_hip_bind(None)
+    L.crc_init(1)
+    da.take_messages()
+    _run_blocks_8000(L, iq)
+    got = da.take_messages()
+    if len(got):
+        got["block"] = (got["block"].astype(np.int64) - int(got["block"][0]) + int(exp["block"][0])).astype(np.uint32)
+    assert len(exp) > 40
+    assert_same_messages(got, exp)
+
+
+def test_demod_8000_with_host_callbacks():
+    iq, _ = synth.capture(65536 * 4 + 999, 8.0e6, "sc16", seed=36, frames_per_sec=2500, bitflip1=0.3, bitflip2=0.1,
+                          ap_fraction=0.3)
+    o = orc.Oracle(8000000, fix_bits=2)
+    o.run_stream(iq, orc.INPUT_SC16, 8000)
+    exp = o.messages()
+    host = orc.Oracle(8000000, fix_bits=2)
+    OL = orc.lib()
+    seen = []
+    hb = da.HostBinding()
+    hb.mm_size = orc.MSG_DTYPE.itemsize
+    hb.off_timestamp_msg, hb.off_sys_timestamp_msg = 0, 8
+    hb.off_sig_level = orc.MSG_DTYPE.fields["sig_level"][1]
+    hb.off_score = orc.MSG_DTYPE.fields["pad2"][1]
+    hb.off_error_bits = orc.MSG_DTYPE.fields["error_bits"][1]
+    hb.off_AC_flags = orc.MSG_DTYPE.fields["pad2"][1]
+    hb.off_addr = orc.MSG_DTYPE.fields["addr"][1]
+    hb.modeS_message_score = da.SCORE_CB(lambda msg, bits: OL.orc_message_score(host.h, msg, bits))
+    hb.decode_mode_S_message = da.DECODE_CB(lambda mm, msg: OL.orc_decode_message(host.h, msg, mm))
+    hb.modeS_user_message = da.USER_CB(lambda mm: seen.append(bytes((C.c_char * hb.mm_size).from_address(mm))))
+    hb.receiveclock_ms_elapsed = da.CLOCK_CB(_elapsed)
+    hb.fix_bits = 2
+    L = da.lib()
+    L.crc_exit()
+    assert L.modes_hip_bind(C.byref(hb)) == 0
+    try:
+        _run_blocks_8000(L, iq)
+    finally:
+        L.modes_hip_bind(None)
+    got = np.frombuffer(b"".join(seen), dtype=orc.MSG_DTYPE)
+    assert len(exp) > 30 and len(got) == len(exp)
+    for f in ("timestamp", "sys_timestamp", "msg_bits", "msg_type", "error_bits", "addr", "crc", "sig_level"):
+        assert np.array_equal(got[f], exp[f]), f
+    for g, x in zip(got, exp):
+        n = int(x["msg_bits"]) // 8
+        assert bytes(g["msg"][:n]) == bytes(x["msg"][:n])
