@@ -169,6 +169,7 @@ struct D8Params {
   D8Window       *windows;       // [nchunks][kD8WinCap]
   Record         *records;       // [nchunks][kD8WinCap][kD8Cand]
   uint32_t        nchunks;
+  uint32_t       *announce;      // [2^24 / 32] addresses that can enter the ICAO cache during the run, or null = no filter
 };
 
 struct EmitParams {

@@ -602,7 +602,7 @@ static bool d8_grow (size_t nsteps, uint32_t nchunks)
     HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.entry), nchunks + 1));
     HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.win_start), nw * sizeof (int64_t)));
     HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.win_count), nchunks * sizeof (uint32_t)));
-    HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.chunk_rec), nchunks * sizeof (uint32_t)));
+    HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.chunk_rec), 2 * size_t (nchunks) * sizeof (uint32_t)));
     HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.windows), nw * sizeof (D8Window)));
     HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.win_packed), nw * sizeof (D8Window)));
     HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.records), nw * kD8Cand * sizeof (Record)));
@@ -653,11 +653,11 @@ static bool demod_8000_locked (const mag_buf *mag, uint32_t block)
   HIP_OK (launch_d8_windows (q, nullptr));
   HIP_OK (launch_d8_tail (q, s.dnext, nullptr));
   HIP_OK (launch_d8_count (q, s.chunk_rec, nullptr));
-  std::vector<uint32_t> wc (nchunks), rcnt (nchunks);
+  std::vector<uint32_t> wc (nchunks), rcnt (2 * size_t (nchunks));
   std::vector<uint64_t> trig (words);
   long long small[8];
   HIP_OK (hipMemcpyAsync (wc.data (), s.win_count, nchunks * sizeof (uint32_t), hipMemcpyDeviceToHost, nullptr));
-  HIP_OK (hipMemcpyAsync (rcnt.data (), s.chunk_rec, nchunks * sizeof (uint32_t), hipMemcpyDeviceToHost, nullptr));
+  HIP_OK (hipMemcpyAsync (rcnt.data (), s.chunk_rec, 2 * size_t (nchunks) * sizeof (uint32_t), hipMemcpyDeviceToHost, nullptr));
   HIP_OK (hipMemcpyAsync (trig.data (), s.trig, words * sizeof (uint64_t), hipMemcpyDeviceToHost, nullptr));
   HIP_OK (hipMemcpyAsync (small, s.small, sizeof small, hipMemcpyDeviceToHost, nullptr));
   HIP_OK (hipStreamSynchronize (nullptr));
@@ -682,7 +682,7 @@ static bool demod_8000_locked (const mag_buf *mag, uint32_t block)
   uint64_t nwin = 0, nrec = 0;
   for (uint32_t c = 0; c < nchunks; c++) {
     if (wc[c] > uint32_t (kD8WinCap)) { set_error (MODES_E_OVERFLOW, "demod_8000: window list overflow"); return false; }
-    off[c] = nwin; off[nchunks + 1 + c] = nrec; nwin += wc[c]; nrec += rcnt[c];
+    off[c] = nwin; off[nchunks + 1 + c] = nrec; nwin += rcnt[nchunks + c]; nrec += rcnt[c];
   }
   if (!nwin) return true;
   HIP_OK (hipMemcpyAsync (s.off, off.data (), off.size () * sizeof (uint64_t), hipMemcpyHostToDevice, nullptr));

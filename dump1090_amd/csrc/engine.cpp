@@ -135,7 +135,7 @@ struct modes_engine {
   size_t nblocks_power = 0;
   // 8 MS/s
   DevBuf<uint64_t> d8_trig, d8_amb, d8_off;
-  DevBuf<uint32_t> d8_p0, d8_mx, d8_win_count, d8_chunk_rec;
+  DevBuf<uint32_t> d8_p0, d8_mx, d8_win_count, d8_chunk_rec, d8_announce;
   DevBuf<uint8_t> d8_table, d8_entry;
   DevBuf<int64_t> d8_win_start, d8_small;
   DevBuf<D8Window> d8_windows, d8_win_packed;
@@ -357,7 +357,7 @@ void modes_engine_destroy (modes_engine *e)
   e->rssi_sum.release (); e->staging.release (); e->tail.release (); e->vp_bitmap.release ();
   e->block_power.release (); e->noise_level.release ();
   e->d8_trig.release (); e->d8_amb.release (); e->d8_off.release (); e->d8_p0.release (); e->d8_mx.release ();
-  e->d8_win_count.release (); e->d8_chunk_rec.release (); e->d8_table.release (); e->d8_entry.release ();
+  e->d8_win_count.release (); e->d8_chunk_rec.release (); e->d8_announce.release (); e->d8_table.release (); e->d8_entry.release ();
   e->d8_win_start.release (); e->d8_small.release (); e->d8_windows.release (); e->d8_win_packed.release ();
   e->d8_records.release (); e->d8_rec_packed.release ();
   if (e->tabs.short_tab) (void) hipFree (e->tabs.short_tab);
@@ -585,7 +585,8 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   if ((rc = e->d8_entry.reserve (nchunks + 1)) != MODES_OK) return rc;
   if ((rc = e->d8_win_start.reserve (size_t (nchunks) * kD8WinCap)) != MODES_OK) return rc;
   if ((rc = e->d8_win_count.reserve (nchunks)) != MODES_OK) return rc;
-  if ((rc = e->d8_chunk_rec.reserve (nchunks)) != MODES_OK) return rc;
+  if ((rc = e->d8_chunk_rec.reserve (2 * size_t (nchunks))) != MODES_OK) return rc;
+  if ((rc = e->d8_announce.reserve ((1u << 24) / 32)) != MODES_OK) return rc;
   if ((rc = e->d8_windows.reserve (size_t (nchunks) * kD8WinCap)) != MODES_OK) return rc;
   if ((rc = e->d8_records.reserve (size_t (nchunks) * kD8WinCap * kD8Cand)) != MODES_OK) return rc;
   if ((rc = e->d8_small.reserve (16)) != MODES_OK) return rc;
@@ -615,19 +616,30 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
     q.write_arrays = 0;
     HIP_TRY (launch_d8_acc (q, limit, nullptr, stream));
   }
+  // addresses the run can know: what the cache starts with, plus every address the window kernel sees announced
+  q.announce = e->d8_announce.p;
+  {
+    std::vector<uint32_t> bits ((1u << 24) / 32, 0u);
+    for (uint32_t i = 0; i < kIcaoSlots; i++) {
+      const uint32_t a = e->cache.raw ()[i] & 0xFFFFFFu;           // the non-ICAO flag (bit 24) never matches a 24-bit test
+      if (e->cache.raw ()[i] && e->cache.raw ()[i] < (1u << 24)) bits[a >> 5] |= 1u << (a & 31);
+    }
+    HIP_TRY (hipMemcpyAsync (q.announce, bits.data (), bits.size () * sizeof (uint32_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY (hipStreamSynchronize (stream));
+  }
   HIP_TRY (launch_d8_chain (q, 0ull, 0ll, d_pre, d_pending, stream));
   HIP_TRY (launch_d8_windows (q, stream));
   HIP_TRY (launch_d8_count (q, e->d8_chunk_rec.p, stream));
-  std::vector<uint32_t> wc (nchunks), rcnt (nchunks);
+  std::vector<uint32_t> wc (nchunks), rcnt (2 * size_t (nchunks));
   HIP_TRY (hipMemcpyAsync (wc.data (), e->d8_win_count.p, nchunks * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
-  HIP_TRY (hipMemcpyAsync (rcnt.data (), e->d8_chunk_rec.p, nchunks * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
+  HIP_TRY (hipMemcpyAsync (rcnt.data (), e->d8_chunk_rec.p, 2 * size_t (nchunks) * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
   HIP_TRY (hipStreamSynchronize (stream));
   std::vector<uint64_t> off (2 * size_t (nchunks) + 2);
   uint64_t nwin = 0, nrec = 0;
   for (uint32_t c = 0; c < nchunks; c++) {
     if (wc[c] > uint32_t (kD8WinCap)) return fail (MODES_E_OVERFLOW, "chunk %u holds %u windows (cap %d)", c, wc[c], kD8WinCap);
     off[c] = nwin; off[nchunks + 1 + c] = nrec;
-    nwin += wc[c]; nrec += rcnt[c];
+    nwin += rcnt[nchunks + c]; nrec += rcnt[c];                    // windows and records that survive the address filter
   }
   e->stats.candidates = nrec;
   if (!nwin) return MODES_OK;

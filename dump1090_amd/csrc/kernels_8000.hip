@@ -438,6 +438,12 @@ void d8_window_kernel (const D8Params q)
         else if (df == 20 || df == 21) cls = kClsAP2;
         else keep = false;
       }
+      // an address only ever enters the ICAO cache through an error-free DF17/18 or DF11 with IID 0
+      // (ref: src/dump1090.c:2676-2687): remember every address that could, for the record filter below
+      if (keep && q.announce && nerr == 0 && (cls == kClsES ? crc == 0 : cls == kClsDF11 && crc == 0)) {
+        uint32_t aa = ((W[0] >> 8) & 0xFF) << 16 | ((W[0] >> 16) & 0xFF) << 8 | (W[0] >> 24);
+        atomicOr (&q.announce[aa >> 5], 1u << (aa & 31));
+      }
       lo4.x = uint32_t (lane) << 16 | (uint32_t (df) << 24);                  // Record.phase = candidate index
       lo4.y = uint32_t (cls) | (uint32_t (uint8_t (nerr)) << 8) | (uint32_t (uint8_t (b0)) << 16) | (uint32_t (uint8_t (b1)) << 24);
       lo4.z = crc; lo4.w = W[0];
@@ -496,6 +502,21 @@ hipError_t launch_d8_last_amb (const uint64_t *amb, uint64_t nwords, unsigned lo
   return hipGetLastError ();
 }
 
+// A record whose score can never reach 0 whatever the run does to the ICAO cache is dead weight for the ordered pass:
+// address/parity formats and DF11 with IID != 0 need their address in the cache (ref: src/dump1090.c:3302-3307,
+// 3332-3338, 3355-3359), and only announced addresses (plus the cache the run started with) can be there.
+__device__ __forceinline__ bool record_relevant (const Record &r, const uint32_t *announce)
+{
+  if (!announce) return true;
+  uint32_t a;
+  if (r.cls == kClsAP || r.cls == kClsAP2) a = r.crc;
+  else if (r.cls == kClsDF11 && (r.crc & 0x7F) != 0) {
+    a = (uint32_t (r.msg[1]) << 16) | (uint32_t (r.msg[2]) << 8) | r.msg[3];
+    if (r.nerr >= 1 && r.bit0 >= 8 && r.bit0 <= 31) a ^= 1u << (31 - r.bit0);
+  } else return true;
+  return a < (1u << 24) && ((announce[a >> 5] >> (a & 31)) & 1);
+}
+
 // ---- compaction of the per-window slots into two dense arrays, window order kept ----
 __global__ __launch_bounds__ (256)
 void d8_count_kernel (const D8Params q, uint32_t *chunk_rec)
@@ -503,31 +524,57 @@ void d8_count_kernel (const D8Params q, uint32_t *chunk_rec)
   __shared__ uint32_t part[256];
   const uint32_t c = blockIdx.x, nwin = min (q.win_count[c], uint32_t (kD8WinCap));
   uint32_t sum = 0;
-  for (uint32_t k = threadIdx.x; k < nwin; k += 256) sum += q.windows[size_t (c) * kD8WinCap + k].nrec;
+  for (uint32_t k = threadIdx.x; k < nwin; k += 256) {
+    D8Window &h = q.windows[size_t (c) * kD8WinCap + k];
+    const Record *src = q.records + (size_t (c) * kD8WinCap + k) * kD8Cand;
+    uint32_t live = 0;
+    for (uint32_t r = 0; r < h.nrec; r++) live += record_relevant (src[r], q.announce);
+    h.pad = live;                                              // records that survive the filter
+    sum += live;
+  }
   part[threadIdx.x] = sum;
   __syncthreads ();
   for (int d = 128; d >= 1; d >>= 1) { if (threadIdx.x < (unsigned) d) part[threadIdx.x] += part[threadIdx.x + d]; __syncthreads (); }
   if (threadIdx.x == 0) chunk_rec[c] = part[0];
+  // windows left with something to score
+  __syncthreads ();
+  uint32_t lw = 0;
+  for (uint32_t k = threadIdx.x; k < nwin; k += 256) lw += q.windows[size_t (c) * kD8WinCap + k].pad != 0;
+  part[threadIdx.x] = lw;
+  __syncthreads ();
+  for (int d = 128; d >= 1; d >>= 1) { if (threadIdx.x < (unsigned) d) part[threadIdx.x] += part[threadIdx.x + d]; __syncthreads (); }
+  if (threadIdx.x == 0) chunk_rec[q.nchunks + c] = part[0];
 }
 
 __global__ __launch_bounds__ (256)
 void d8_gather_kernel (const D8Params q, const uint64_t *win_off, const uint64_t *rec_off, D8Window *win_out, Record *rec_out)
 {
-  __shared__ uint32_t pre[kD8WinCap + 1];
+  __shared__ uint32_t pre[kD8WinCap + 1], wpre[kD8WinCap + 1];
   const uint32_t c = blockIdx.x, nwin = min (q.win_count[c], uint32_t (kD8WinCap));
   if (threadIdx.x == 0) {
-    uint32_t run = 0;
-    for (uint32_t k = 0; k < nwin; k++) { pre[k] = run; run += q.windows[size_t (c) * kD8WinCap + k].nrec; }
+    uint32_t run = 0, wrun = 0;
+    for (uint32_t k = 0; k < nwin; k++) {
+      const uint32_t live = q.windows[size_t (c) * kD8WinCap + k].pad;
+      pre[k] = run; wpre[k] = wrun; run += live; wrun += live != 0;
+    }
   }
   __syncthreads ();
   for (uint32_t k = threadIdx.x; k < nwin; k += 256) {
     D8Window h = q.windows[size_t (c) * kD8WinCap + k];
+    if (!h.pad) continue;
     const uint64_t ro = rec_off[c] + pre[k];
-    const uint4 *src = reinterpret_cast<const uint4 *> (q.records + (size_t (c) * kD8WinCap + k) * kD8Cand);
-    uint4 *dst = reinterpret_cast<uint4 *> (rec_out + ro);
-    for (uint32_t r = 0; r < 2 * h.nrec; r++) dst[r] = src[r];
+    const Record *src = q.records + (size_t (c) * kD8WinCap + k) * kD8Cand;
+    uint32_t n = 0;
+    for (uint32_t r = 0; r < h.nrec; r++)
+      if (record_relevant (src[r], q.announce)) {
+        const uint4 *s4 = reinterpret_cast<const uint4 *> (src + r);
+        uint4 *d4 = reinterpret_cast<uint4 *> (rec_out + ro + n);
+        d4[0] = s4[0]; d4[1] = s4[1];
+        n++;
+      }
+    h.nrec = n;
     h.pad = uint32_t (ro);
-    win_out[win_off[c] + k] = h;
+    win_out[win_off[c] + wpre[k]] = h;
   }
 }
 
