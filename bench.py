@@ -1,8 +1,16 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the 2.4 MS/s path (BASELINE.json configs[1]).
+"""bench.py -- throughput of the raw-IQ hot path on MI355X (BASELINE.json).
 
-One "step" = one pass of the whole hot path (IQ resident in HBM -> ordered message list on the
-host) over one synthetic recording.  Prints ONE JSON line on rank 0.
+One "step" = one pass of the whole hot path (IQ resident in HBM -> ordered message list in host memory)
+over one synthetic recording (or, for the Mode A/C batch, over the rank's recordings back to back).
+Prints ONE JSON line on rank 0.
+
+Workloads (BASELINE.json `configs`):
+  uc8_2400      configs[1]  synthetic 2.4 MS/s uc8, 4 GiB, DF11/DF17 at mixed SNR        (default, the headline)
+  sc16_2400                 the same signal as sc16 (the converter that decodes: see DESIGN.md 7)
+  sc16_2000     configs[2]  2.0 MS/s demod_2000, 1- and 2-bit CRC repair, dense traffic
+  sc16_8000     configs[3]  8 MS/s demod_8000, this rank's 4 GiB shard of the 32 GiB capture
+  sc16_2400ac   configs[4]  demod_2400 + demod_2400_AC on a batch of 256 MiB recordings (64 / N per rank)
 """
 import argparse
 import json
@@ -21,6 +29,126 @@ from dump1090_amd import synth_torch          # noqa: E402
 
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8 TB/s spec
 
+WORKLOADS = {
+    #               rate      fmt     engine kwargs                       traffic              kernel
+    "uc8_2400":    (2400000, "uc8",  {"fix_bits": 1},                    {"frames_per_sec": 1000.0}, "scan2400_kernel"),
+    "sc16_2400":   (2400000, "sc16", {"fix_bits": 1},                    {"frames_per_sec": 1000.0}, "scan2400_kernel"),
+    "sc16_2000":   (2000000, "sc16", {"fix_bits": 2},                    {"frames_per_sec": 5000.0}, "scan2000_kernel"),
+    "sc16_8000":   (8000000, "sc16", {"fix_bits": 1},                    {"frames_per_sec": 1000.0}, "d8_window_kernel"),
+    "sc16_2400ac": (2400000, "sc16", {"fix_bits": 1, "mode_ac": True},   {"frames_per_sec": 1000.0}, "scan2400_kernel"),
+}
+CONV_ROW = {("uc8", False): 0, ("uc8", True): 1, ("sc16", False): 3, ("sc16", True): 4}
+
+
+def run_workload(name, args, world, rank, local, dev, want_cpu):
+    rate, fmt, ekw, traffic, kernel = WORKLOADS[name]
+    import torch.distributed as dist
+    bps = 2 if fmt == "uc8" else 4
+    power = args.converter == "power"
+    if name == "sc16_2400ac":
+        nrec = max(1, 64 // world)
+        nsamples = (256 << 20) // bps
+    else:
+        nrec = 1
+        nsamples = int(args.gib * (1 << 30)) // bps
+    fmt_id = da.INPUT_UC8 if fmt == "uc8" else da.INPUT_SC16
+    t0 = time.time()
+    recs = []
+    for r in range(nrec):
+        iq, info = synth_torch.capture_gpu(nsamples, float(rate), fmt, seed=1 + rank * 64 + r, device=dev, **traffic)
+        recs.append((iq, info))
+    torch.cuda.synchronize()
+    gen_s = time.time() - t0
+    nbytes = recs[0][0].numel() * recs[0][0].element_size()
+    eng = da.Engine(rate, fmt_id, compute_power=power, device=local, **ekw)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_step():
+        nm, kms, k2 = 0, 0.0, 0.0
+        for iq, _ in recs:
+            eng.set_icao(None)                # every recording is decoded from a cold ICAO cache
+            eng.run_device(iq.data_ptr(), nbytes, stream=stream)
+            nm += eng.num_messages()
+            a, b = eng.kernel_ms()
+            kms += a
+            k2 += b
+        return nm, kms, k2
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    kms = k2 = 0.0
+    nm = 0
+    for _ in range(args.steps):
+        nm, a, b = one_step()
+        kms += a
+        k2 += b
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    msgs = eng.messages()
+    stats = eng.stats()
+    nmsg = torch.tensor([nm], device=dev, dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(nmsg)
+    step_s = dt / args.steps
+    value = world * nrec * nsamples / step_s / 1e6               # Msamples/s, whole job
+
+    # dominant kernel: HIP events on the launch stream around it, averaged over the timed steps
+    kernel_ms = kms / args.steps / nrec                           # per launch
+    # algorithmic bytes per sample (DESIGN.md 5): the IQ bytes the selected converter has to read
+    alg_bps = 1 if (fmt == "uc8" and not power) else bps
+    achieved = nsamples * alg_bps / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": args.traffic, "kernel": kernel,
+                "kernel_ms": round(kernel_ms, 4), "alg_bytes_per_sample": alg_bps}
+    if k2:
+        roofline["second_kernel"] = {"kernel": "d8_trig_kernel", "kernel_ms": round(k2 / args.steps / nrec, 4)}
+
+    cpu = None
+    if want_cpu:
+        from oracle import orc
+        iq0 = recs[-1][0]
+        # bounded sample of the same recording: whole 256 KiB blocks from the start
+        nblk = max(8, int(args.cpu_seconds * 35e6 / (262144 // bps)))
+        nblk = min(nblk, nbytes // 262144)
+        host = iq0[: nblk * 262144 // iq0.element_size()].cpu().numpy()
+        o = orc.Oracle(rate, fix_bits=ekw.get("fix_bits", 1), measure_noise=power)
+        t0 = time.perf_counter()
+        o.run_stream(host, orc.INPUT_UC8 if fmt == "uc8" else orc.INPUT_SC16, rate // 1000, compute_power=power,
+                     also_ac=bool(ekw.get("mode_ac")))
+        cdt = time.perf_counter() - t0
+        cpu_msgs = o.messages()
+        # prefix parity: the engine's messages of those blocks must be the oracle's.  (demod_8000 messages near the cut
+        # belong to windows the shorter stream never completes: compare all but the last block there.)
+        lim = nblk - (1 if rate == 8000000 else 0)
+        g, c = msgs[msgs["block"] < lim], cpu_msgs[cpu_msgs["block"] < lim]
+        parity = bool(len(g) == len(c) and np.array_equal(g["timestamp"], c["timestamp"])
+                      and np.array_equal(g["crc"], c["crc"]))
+        cpu = {"value": round(nblk * (262144 // bps) / cdt / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": "port",
+               "sample": "first %d blocks (%d MiB) of the same recording, oracle/ C restatement, 1 thread"
+                         % (nblk, nblk // 4), "msgs": int(len(cpu_msgs)), "prefix_parity": parity}
+
+    conv_name = da.CONVERTER_NAMES[CONV_ROW[(fmt, power)]]
+    return {
+        "value": round(value, 1), "ms_per_step": round(step_s * 1e3, 3),
+        "config": {"workload": "%s: synthetic %.1f MS/s %s IQ, %d x %.2f GiB per GPU, injected DF11/DF17 frames at mixed SNR"
+                               % (name, rate / 1e6, fmt, nrec, nbytes / (1 << 30)),
+                   "converter": conv_name, "demod": "demod_%d%s" % (rate // 1000, "+demod_2400_AC" if ekw.get("mode_ac") else ""),
+                   "fix_bits": ekw.get("fix_bits", 1), "frames_injected_per_gpu": int(sum(len(i["pos"]) for _, i in recs))},
+        "msgs": int(nmsg.item()), "msgs_per_s": round(int(nmsg.item()) / step_s, 1),
+        "valid_preamble": stats["valid_preamble"], "candidates": stats["candidates"],
+        "roofline": roofline, "cpu_baseline": cpu, "gen_seconds": round(gen_s, 1)}
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -28,11 +156,13 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--gib", type=float, default=4.0, help="IQ bytes per GPU, GiB")
-    ap.add_argument("--format", default="uc8", choices=["uc8", "sc16"])
+    ap.add_argument("--workload", default="uc8_2400", choices=sorted(WORKLOADS))
     ap.add_argument("--converter", default="reference", choices=["reference", "power"],
                     help="reference = convert_init(fmt, DC off, power off); power = compute_power=1")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the companion sc16 line of the default workload")
+    ap.add_argument("--traffic", type=float, default=None, help="HBM bytes per launch of the roofline kernel from PMC counters")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -44,91 +174,27 @@ def main():
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
 
-    bps = 2 if args.format == "uc8" else 4
-    nsamples = int(args.gib * (1 << 30)) // bps
-    fmt = da.INPUT_UC8 if args.format == "uc8" else da.INPUT_SC16
-    t0 = time.time()
-    iq, info = synth_torch.capture_gpu(nsamples, 2.4e6, args.format, seed=1 + rank, device=dev)
-    torch.cuda.synchronize()
-    gen_s = time.time() - t0
-    nbytes = iq.numel() * iq.element_size()
-
-    eng = da.Engine(2400000, fmt, compute_power=(args.converter == "power"), fix_bits=1, device=local)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        eng.set_icao(None)                    # every step decodes the recording from a cold ICAO cache
-        eng.run_device(iq.data_ptr(), nbytes, stream=stream)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.set_icao(None)
-        eng.run_device(iq.data_ptr(), nbytes, stream=stream)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    msgs = eng.messages()
-    stats = eng.stats()
-    nmsg = torch.tensor([len(msgs)], device=dev, dtype=torch.int64)
-    if world > 1:
-        dist.all_reduce(nmsg)
-    ms_per_step = dt / args.steps * 1e3
-    value = world * nsamples / (dt / args.steps) / 1e6            # Msamples/s, whole job
-
-    # dominant kernel: the fused scan kernel, HIP events on the launch stream
-    scan_ms = eng.time_scan(iq.data_ptr(), nbytes, reps=5, stream=stream)
-    # algorithmic bytes per sample (DESIGN.md): the IQ bytes the selected converter has to read
-    alg_bps = 1 if (args.format == "uc8" and args.converter == "reference") else bps
-    achieved = nsamples * alg_bps / (scan_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "scan2400_kernel",
-                "kernel_ms": round(scan_ms, 4), "alg_bytes_per_sample": alg_bps}
-
-    cpu = None
-    if rank == 0 and not args.no_cpu:
-        from oracle import orc
-        # bounded sample of the same recording: whole 256 KiB blocks from the start
-        nblk = max(8, int(args.cpu_seconds * 35e6 / (262144 // bps)))
-        nblk = min(nblk, nbytes // 262144)
-        host = iq[: nblk * 262144 // iq.element_size()].cpu().numpy()
-        o = orc.Oracle(2400000, fix_bits=1, measure_noise=(args.converter == "power"))
-        t0 = time.perf_counter()
-        o.run_stream(host, orc.INPUT_UC8 if args.format == "uc8" else orc.INPUT_SC16, 2400,
-                     compute_power=(args.converter == "power"))
-        cdt = time.perf_counter() - t0
-        cpu_msgs = o.messages()
-        # prefix parity: the engine's messages of those blocks must be the oracle's
-        g = msgs[msgs["block"] < nblk] if world == 1 else None
-        parity = None
-        if g is not None:
-            parity = bool(len(g) == len(cpu_msgs) and np.array_equal(g["timestamp"], cpu_msgs["timestamp"]))
-        cpu = {"value": round(nblk * (262144 // bps) / cdt / 1e6, 2), "unit": "Msamples/s", "cores": 1, "kind": "port",
-               "sample": "first %d blocks (%d MiB) of the same recording, oracle/ C restatement, 1 thread"
-                         % (nblk, nblk // 4), "msgs": int(len(cpu_msgs)), "prefix_parity": parity}
+    res = run_workload(args.workload, args, world, rank, local, dev, want_cpu=(rank == 0 and world == 1 and not args.no_cpu))
+    also = None
+    if args.workload == "uc8_2400" and not args.no_also:
+        # the reference-selected uc8 converter reads one byte per sample and decodes nothing from IQ;
+        # the same signal as sc16 shows the path with its messages
+        args2 = argparse.Namespace(**vars(args))
+        args2.cpu_seconds = 5.0
+        r2 = run_workload("sc16_2400", args2, world, rank, local, dev, want_cpu=(rank == 0 and world == 1 and not args.no_cpu))
+        also = {k: r2[k] for k in ("value", "ms_per_step", "config", "msgs", "msgs_per_s", "roofline", "cpu_baseline")}
 
     if rank == 0:
-        conv_name = da.CONVERTER_NAMES[{"uc8": {"reference": 0, "power": 1}, "sc16": {"reference": 3, "power": 4}}
-                                       [args.format][args.converter]]
-        print(json.dumps({
-            "metric": "Msamples/s decoded (+ msgs/s) at 2.4 MS/s uc8", "value": round(value, 1),
-            "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u16", "data": "synthetic",
-            "config": {"workload": "synthetic 2.4 MS/s %s IQ, %.2f GiB per GPU, injected DF11/DF17 frames at mixed SNR"
-                                   % (args.format, args.gib), "converter": conv_name, "demod": "demod_2400",
-                       "fix_bits": 1, "frames_injected_per_gpu": int(len(info["pos"]))},
-            "msgs": int(nmsg.item()), "msgs_per_s": round(int(nmsg.item()) / (dt / args.steps), 1),
-            "valid_preamble": stats["valid_preamble"], "candidates": stats["candidates"],
-            "roofline": roofline, "cpu_baseline": cpu, "gen_seconds": round(gen_s, 1)}))
+        out = {"metric": "Msamples/s decoded (+ msgs/s) at 2.4 MS/s uc8", "value": res["value"], "unit": "Msamples/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic"}
+        out.update({k: res[k] for k in ("config", "msgs", "msgs_per_s", "valid_preamble", "candidates", "roofline",
+                                        "cpu_baseline", "gen_seconds")})
+        if also:
+            out["also"] = also
+        print(json.dumps(out))
     if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 

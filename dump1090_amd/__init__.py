@@ -116,6 +116,7 @@ def lib():
         L.modes_engine_messages.restype = C.c_void_p
         L.modes_engine_messages.argtypes = [C.c_void_p]
         L.modes_engine_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.modes_engine_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.modes_engine_block_power.restype = C.c_size_t
         L.modes_engine_block_power.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.modes_engine_tail_halo.restype = C.c_void_p
@@ -197,12 +198,21 @@ class Engine:
                                              C.c_void_p(stream) if stream else None, C.byref(ms)))
         return ms.value
 
+    def num_messages(self):
+        return int(self.L.modes_engine_num_messages(self.h))
+
     def messages(self):
         n = self.L.modes_engine_num_messages(self.h)
         if n == 0:
             return np.zeros(0, dtype=MESSAGE_DTYPE)
         buf = (C.c_char * (n * MESSAGE_DTYPE.itemsize)).from_address(self.L.modes_engine_messages(self.h))
         return np.frombuffer(buf, dtype=MESSAGE_DTYPE).copy()
+
+    def kernel_ms(self):
+        """(main, second) kernel durations of the last run in ms (HIP events on the launch stream)."""
+        a, b = C.c_float(), C.c_float()
+        _check(self.L.modes_engine_kernel_ms(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def block_power(self):
         """mean_power of every block of the last run (only computed with mode_ac at 2.4 MS/s)."""

@@ -647,7 +647,7 @@ static bool demod_8000_locked (const mag_buf *mag, uint32_t block)
   const size_t words = size_t (nsteps / 64 + 64);
   HIP_OK (hipMemsetAsync (q.trig, 0, words * sizeof (uint64_t), nullptr));
   HIP_OK (hipMemsetAsync (q.amb, 0, words * sizeof (uint64_t), nullptr));
-  HIP_OK (launch_d8_trig (q, nullptr));
+  HIP_OK (launch_d8_trig (q, 0, nullptr));
   HIP_OK (launch_d8_acc (q, nsteps, d_acc, nullptr));           // the running average is carried to the next call: always formed
   HIP_OK (launch_d8_chain (q, s.trig_tail, 0ll, d_pre, d_pending, nullptr));
   HIP_OK (launch_d8_windows (q, nullptr));

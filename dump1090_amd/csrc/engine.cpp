@@ -133,6 +133,9 @@ struct modes_engine {
   DevBuf<double> block_power;
   DevBuf<uint32_t> noise_level;
   size_t nblocks_power = 0;
+  // HIP events around the dominant kernel(s) of the last run, recorded on the launch stream
+  hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+  float kernel_ms[2] = { 0, 0 };
   // 8 MS/s
   DevBuf<uint64_t> d8_trig, d8_amb, d8_off;
   DevBuf<uint32_t> d8_p0, d8_mx, d8_win_count, d8_chunk_rec, d8_announce;
@@ -343,6 +346,8 @@ int modes_engine_create (const modes_engine_config *cfg, modes_engine **out)
   if (rc != MODES_OK) { modes_engine_destroy (e); return rc; }
   rc = e->tail.reserve (e->ov);
   if (rc != MODES_OK) { modes_engine_destroy (e); return rc; }
+  for (hipEvent_t &ev : e->ev)
+    if (hipEventCreate (&ev) != hipSuccess) { modes_engine_destroy (e); return fail (MODES_E_HIP, "hipEventCreate failed"); }
   *out = e;
   return MODES_OK;
 }
@@ -368,6 +373,7 @@ void modes_engine_destroy (modes_engine *e)
   if (e->tabs.log10_lut) (void) hipFree (e->tabs.log10_lut);
   if (e->tabs.crc_table) (void) hipFree (e->tabs.crc_table);
   if (e->d_stats) (void) hipFree (e->d_stats);
+  for (hipEvent_t ev : e->ev) if (ev) (void) hipEventDestroy (ev);
   delete e;
 }
 
@@ -400,7 +406,9 @@ static int run_device_inner (modes_engine *e, const void *d_iq, size_t nbytes, u
   if (rc != MODES_OK) return rc;
   if (sp.nstrips == 0) return MODES_OK;
 
+  HIP_TRY (hipEventRecord (e->ev[0], stream));
   HIP_TRY (e->mode == 2000 ? launch_scan2000 (sp, stream) : launch_scan2400 (sp, stream));
+  HIP_TRY (hipEventRecord (e->ev[1], stream));
 
   // totals, then compact the per-strip slots into one ordered list
   const uint32_t nchunks = (sp.nstrips + 1023) / 1024;
@@ -414,6 +422,8 @@ static int run_device_inner (modes_engine *e, const void *d_iq, size_t nbytes, u
   unsigned long long st[3];
   HIP_TRY (hipMemcpyAsync (st, d_totals, sizeof st, hipMemcpyDeviceToHost, stream));
   HIP_TRY (hipStreamSynchronize (stream));
+  (void) hipEventElapsedTime (&e->kernel_ms[0], e->ev[0], e->ev[1]);
+  e->kernel_ms[1] = 0;
   if (st[2]) return fail (MODES_E_OVERFLOW, "%llu strips overflowed their candidate slots (cap %u)", st[2], e->cap);
   const size_t nrec = size_t (st[0]);
   e->stats.valid_preamble = st[1];
@@ -602,7 +612,9 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   HIP_TRY (hipMemcpyAsync (d_pre, init, sizeof init, hipMemcpyHostToDevice, stream));
   HIP_TRY (hipMemsetAsync (q.trig, 0, nwords * sizeof (uint64_t), stream));
   HIP_TRY (hipMemsetAsync (q.amb, 0, nwords * sizeof (uint64_t), stream));
-  HIP_TRY (launch_d8_trig (q, stream));
+  HIP_TRY (hipEventRecord (e->ev[2], stream));
+  HIP_TRY (launch_d8_trig (q, 0, stream));
+  HIP_TRY (hipEventRecord (e->ev[3], stream));
   HIP_TRY (launch_d8_last_amb (q.amb, nwords, d_limit, stream));
   unsigned long long limit = 0;
   HIP_TRY (hipMemcpyAsync (&limit, d_limit, sizeof limit, hipMemcpyDeviceToHost, stream));
@@ -612,7 +624,7 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
     if ((rc = e->d8_p0.reserve (size_t (q.nsteps) + 64)) != MODES_OK) return rc;
     if ((rc = e->d8_mx.reserve (size_t (q.nsteps) + 64)) != MODES_OK) return rc;
     q.p0 = e->d8_p0.p; q.mx = e->d8_mx.p; q.write_arrays = 1;
-    HIP_TRY (launch_d8_trig (q, stream));
+    HIP_TRY (launch_d8_trig (q, limit, stream));                  // only the strips up to the last such step
     q.write_arrays = 0;
     HIP_TRY (launch_d8_acc (q, limit, nullptr, stream));
   }
@@ -628,12 +640,16 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
     HIP_TRY (hipStreamSynchronize (stream));
   }
   HIP_TRY (launch_d8_chain (q, 0ull, 0ll, d_pre, d_pending, stream));
+  HIP_TRY (hipEventRecord (e->ev[0], stream));
   HIP_TRY (launch_d8_windows (q, stream));
+  HIP_TRY (hipEventRecord (e->ev[1], stream));
   HIP_TRY (launch_d8_count (q, e->d8_chunk_rec.p, stream));
   std::vector<uint32_t> wc (nchunks), rcnt (2 * size_t (nchunks));
   HIP_TRY (hipMemcpyAsync (wc.data (), e->d8_win_count.p, nchunks * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
   HIP_TRY (hipMemcpyAsync (rcnt.data (), e->d8_chunk_rec.p, 2 * size_t (nchunks) * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
   HIP_TRY (hipStreamSynchronize (stream));
+  (void) hipEventElapsedTime (&e->kernel_ms[0], e->ev[0], e->ev[1]);
+  (void) hipEventElapsedTime (&e->kernel_ms[1], e->ev[2], e->ev[3]);
   std::vector<uint64_t> off (2 * size_t (nchunks) + 2);
   uint64_t nwin = 0, nrec = 0;
   for (uint32_t c = 0; c < nchunks; c++) {
@@ -739,6 +755,14 @@ int modes_engine_get_stats (const modes_engine *e, modes_stats *out)
 {
   if (!e || !out) return fail (MODES_E_ARG, "null argument");
   *out = e->stats;
+  return MODES_OK;
+}
+
+int modes_engine_kernel_ms (const modes_engine *e, float *main_ms, float *second_ms)
+{
+  if (!e) return fail (MODES_E_ARG, "null engine");
+  if (main_ms) *main_ms = e->kernel_ms[0];
+  if (second_ms) *second_ms = e->kernel_ms[1];
   return MODES_OK;
 }
 

@@ -16,7 +16,7 @@ hipError_t launch_noise_level (const double *mean_power, uint32_t nblocks, uint3
 hipError_t launch_block_power (const ScanParams &p, uint32_t nblocks, double *mean_power, hipStream_t stream);
 // kernels_8000.hip
 hipError_t upload_constants_8000 (const uint32_t *single_bit, const float *uc8_float);
-hipError_t launch_d8_trig (const D8Params &q, hipStream_t stream);
+hipError_t launch_d8_trig (const D8Params &q, uint64_t step_limit, hipStream_t stream);
 hipError_t launch_d8_acc (const D8Params &q, uint64_t limit, int32_t *acc_out, hipStream_t stream);
 hipError_t launch_d8_last_amb (const uint64_t *amb, uint64_t nwords, unsigned long long *limit, hipStream_t stream);
 hipError_t launch_d8_chain (const D8Params &q, unsigned long long trig_tail, long long search0, long long *pre,

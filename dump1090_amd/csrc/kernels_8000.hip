@@ -70,9 +70,11 @@ struct TrigLds {
 };
 
 struct WinLds {
-  uint16_t tile[kWinTile];
+  union {                                   // the magnitudes are dead once the differences are formed
+    uint16_t tile[kWinTile];
+    uint32_t c[(224 + 1) * 8];
+  };
   int32_t  dw[kWinRows * 8 + 8];
-  uint32_t c[(224 + 1) * 8];
   uint32_t tot[64];
   int32_t  match[kD8Win];
   uint8_t  par[kD8Win + 8];
@@ -111,7 +113,7 @@ __device__ __forceinline__ int table_lookup8 (const ErrEntry *tab, int n, uint32
 // ---------------------------------------------------------------------------------------------
 template <int CONV>
 __global__ __launch_bounds__ (64 * kW8)
-void d8_trig_kernel (const D8Params q)
+void d8_trig_kernel (const D8Params q, uint64_t strip_limit)
 {
   __shared__ TrigLds lds[kW8];
   const int lane = lane_id ();
@@ -119,7 +121,7 @@ void d8_trig_kernel (const D8Params q)
   TrigLds &w = lds[wv];
   const uint64_t nstrips = (q.nsteps + kD8StripSteps - 1) / kD8StripSteps;
   const uint64_t strip = uint64_t (blockIdx.x) * kW8 + wv;
-  if (strip >= nstrips) return;
+  if (strip >= nstrips || strip >= strip_limit) return;
   for (int i = lane; i < 256; i += 64) w.lut[i] = q.sp.lut256 ? q.sp.lut256[i] : uint16_t (0);
 
   const long long n0 = (long long) strip * kD8StripSteps;
@@ -607,12 +609,14 @@ hipError_t upload_constants_8000 (const uint32_t *single_bit, const float *uc8_f
     default: return hipErrorInvalidValue;                                                                           \
   }
 
-hipError_t launch_d8_trig (const D8Params &q, hipStream_t stream)
+// step_limit: only the strips that hold steps below it (0 = all)
+hipError_t launch_d8_trig (const D8Params &q, uint64_t step_limit, hipStream_t stream)
 {
   if (q.nsteps == 0) return hipSuccess;
-  const uint64_t nstrips = (q.nsteps + kD8StripSteps - 1) / kD8StripSteps;
+  uint64_t nstrips = (q.nsteps + kD8StripSteps - 1) / kD8StripSteps;
+  if (step_limit) nstrips = min (nstrips, (step_limit + kD8StripSteps - 1) / kD8StripSteps);
   const dim3 grid ((unsigned) ((nstrips + kW8 - 1) / kW8)), block (64 * kW8);
-  D8_DISPATCH (d8_trig_kernel, grid, block, q);
+  D8_DISPATCH (d8_trig_kernel, grid, block, q, nstrips);
   return hipGetLastError ();
 }
 

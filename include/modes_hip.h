@@ -219,6 +219,10 @@ int  modes_engine_run_host (modes_engine *e, const void *iq, size_t nbytes, uint
  * kernel duration.  For roofline measurements. */
 int  modes_engine_time_scan (modes_engine *e, const void *d_iq, size_t nbytes, int reps, void *stream, float *ms_out);
 
+/* Duration of the dominant kernel of the last run, from HIP events recorded on the launch stream around it:
+ * main_ms = the scan kernel (2.0 / 2.4 MS/s) or the window kernel (8 MS/s); second_ms = the 8 MS/s trigger kernel, else 0. */
+int  modes_engine_kernel_ms (const modes_engine *e, float *main_ms, float *second_ms);
+
 size_t               modes_engine_num_messages (const modes_engine *e);
 const modes_message *modes_engine_messages (const modes_engine *e);      /* host memory */
 int                  modes_engine_get_stats (const modes_engine *e, modes_stats *out);
