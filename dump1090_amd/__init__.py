@@ -119,6 +119,7 @@ def lib():
         L.modes_engine_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.modes_engine_block_power.restype = C.c_size_t
         L.modes_engine_block_power.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.modes_engine_halo_at.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p, C.c_void_p]
         L.modes_engine_tail_halo.restype = C.c_void_p
         L.modes_engine_tail_halo.argtypes = [C.c_void_p]
         L.modes_convert_device.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(ConvertState),
@@ -197,6 +198,13 @@ class Engine:
         _check(self.L.modes_engine_time_scan(self.h, C.c_void_p(data_ptr), nbytes, reps,
                                              C.c_void_p(stream) if stream else None, C.byref(ms)))
         return ms.value
+
+    def halo_at(self, data_ptr, nbytes, at_sample, out_ptr, stream=None):
+        _check(self.L.modes_engine_halo_at(self.h, C.c_void_p(data_ptr), nbytes, at_sample, C.c_void_p(out_ptr),
+                                           C.c_void_p(stream) if stream else None))
+
+    def tail_halo(self):
+        return self.L.modes_engine_tail_halo(self.h)
 
     def num_messages(self):
         return int(self.L.modes_engine_num_messages(self.h))

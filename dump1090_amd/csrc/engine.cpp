@@ -409,6 +409,7 @@ static int run_device_inner (modes_engine *e, const void *d_iq, size_t nbytes, u
   HIP_TRY (hipEventRecord (e->ev[0], stream));
   HIP_TRY (e->mode == 2000 ? launch_scan2000 (sp, stream) : launch_scan2400 (sp, stream));
   HIP_TRY (hipEventRecord (e->ev[1], stream));
+  HIP_TRY (launch_tail (sp, sp.nsamples, e->tail.p, stream));        // what a following shard needs as d_halo
 
   // totals, then compact the per-strip slots into one ordered list
   const uint32_t nchunks = (sp.nstrips + 1023) / 1024;
@@ -778,6 +779,19 @@ size_t modes_engine_block_power (modes_engine *e, double *out, size_t max)
 }
 
 const uint16_t *modes_engine_tail_halo (const modes_engine *e) { return e ? e->tail.p : nullptr; }
+
+int modes_engine_halo_at (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t at_sample, uint16_t *d_out, void *stream_v)
+{
+  if (!e || !d_iq || !d_out) return fail (MODES_E_ARG, "null argument");
+  HIP_TRY (hipSetDevice (e->cfg.device));
+  ScanParams sp;
+  memset (&sp, 0, sizeof sp);
+  sp.iq = static_cast<const uint8_t *> (d_iq);
+  sp.nsamples = nbytes / bytes_per_sample (e->cfg.input_format);
+  sp.ov = e->ov; sp.block_samples = e->block_samples; sp.conv = e->conv; sp.lut256 = e->tabs.lut256;
+  HIP_TRY (launch_tail (sp, at_sample, d_out, static_cast<hipStream_t> (stream_v)));
+  return MODES_OK;
+}
 
 int modes_convert_device (int conv, const void *d_iq, uint16_t *d_mag, size_t nsamples, convert_state *state,
                           double *out_power, void *stream_v)

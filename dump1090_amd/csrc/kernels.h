@@ -6,6 +6,7 @@
 namespace modes {
 hipError_t upload_constants (const uint32_t *single_bit, const float *uc8_float);
 hipError_t launch_scan2400 (const ScanParams &p, hipStream_t stream);
+hipError_t launch_tail (const ScanParams &p, uint64_t at, uint16_t *out, hipStream_t stream);
 // kernels_2000.hip
 hipError_t upload_constants_2000 (const uint32_t *single_bit, const float *uc8_float);
 hipError_t launch_scan2000 (const ScanParams &p, hipStream_t stream);

@@ -896,6 +896,32 @@ void emit2400_kernel (const EmitParams p)
   }
 }
 
+// `ov` magnitudes of the virtual stream starting at V[at]: with at = nsamples this is what fifo_enqueue keeps for the
+// next block (ref: src/fifo.c:205-211), i.e. the halo of a following shard
+template <int CONV>
+__global__ __launch_bounds__ (256)
+void tail_kernel (const ScanParams p, uint64_t at, uint16_t *out)
+{
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.ov) return;
+  out[i] = mag_of_V<CONV> (p.iq, p.nsamples, p.halo, p.ov, p.block_samples, p.lut256, (long long) (at + i));
+}
+
+hipError_t launch_tail (const ScanParams &p, uint64_t at, uint16_t *out, hipStream_t stream)
+{
+  if (!p.ov) return hipSuccess;
+  const dim3 grid ((p.ov + 255) / 256), block (256);
+  switch (p.conv) {
+    case kConvUc8Lut: case kConvUc8LutPower: hipLaunchKernelGGL (tail_kernel<kConvUc8Lut>, grid, block, 0, stream, p, at, out); break;
+    case kConvUc8Generic:     hipLaunchKernelGGL (tail_kernel<kConvUc8Generic>, grid, block, 0, stream, p, at, out); break;
+    case kConvSc16Int:        hipLaunchKernelGGL (tail_kernel<kConvSc16Int>, grid, block, 0, stream, p, at, out); break;
+    case kConvSc16Generic:    hipLaunchKernelGGL (tail_kernel<kConvSc16Generic>, grid, block, 0, stream, p, at, out); break;
+    case kConvSc16Q11Generic: hipLaunchKernelGGL (tail_kernel<kConvSc16Q11Generic>, grid, block, 0, stream, p, at, out); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError ();
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers (called from engine.cpp)
 // ------------------------------------------------------------------------------------------

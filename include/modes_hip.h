@@ -232,6 +232,11 @@ size_t               modes_engine_block_power (modes_engine *e, double *out, siz
 /* the last block's trailing `overlap` magnitudes (device memory), to pass as d_halo of the next shard */
 const uint16_t      *modes_engine_tail_halo (const modes_engine *e);
 
+/* The `overlap` magnitudes that precede sample `at_sample` of the IQ in d_iq (zeros before sample 0), written to
+ * d_out (device): the d_halo of a shard that starts at `at_sample`, for callers that decode shards in parallel and so
+ * cannot wait for the previous shard's tail.  at_sample must be a multiple of the block length. */
+int  modes_engine_halo_at (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t at_sample, uint16_t *d_out, void *stream);
+
 /* Stand-alone converter on device buffers: what convert_func computes, for n samples. */
 int  modes_convert_device (int converter_id /* row of converters_table, ref: src/convert.c:301-308 */,
                            const void *d_iq, uint16_t *d_mag, size_t nsamples,

@@ -202,6 +202,9 @@ struct orc_ctx {
   orc_stats st;
   orc_msg *msgs; size_t nmsgs, capmsgs;
   int cur_block;
+  /* where the next orc_run_stream starts (a shard of a longer recording): sample counter and the magnitudes
+   * `fifo_enqueue` would carry over from the block before (ref: src/fifo.c:195-211) */
+  uint64_t start_counter; uint16_t *start_tail; uint32_t start_tail_n;
   /* demod_8000 file-static state (ref: src/demod-8000.c:80-89) */
   int *d8_dbuf; size_t d8_dbuf_len;
   int d8_acc, d8_bt_acc, d8_window, d8_win_start, d8_start_phase;
@@ -232,8 +235,21 @@ orc_ctx *orc_create (uint32_t sample_rate, int fix_bits, int phase_enhance, int 
 void orc_destroy (orc_ctx *c)
 {
   if (!c) return;
-  free (c->short_tab); free (c->long_tab); free (c->msgs); free (c->d8_dbuf); free (c);
+  free (c->short_tab); free (c->long_tab); free (c->msgs); free (c->d8_dbuf); free (c->start_tail); free (c);
 }
+
+/* test support for sharded runs: start the next stream at sample `counter` with `tail` as the carried overlap */
+void orc_stream_start (orc_ctx *c, uint64_t counter, const uint16_t *tail, uint32_t n)
+{
+  free (c->start_tail);
+  c->start_tail = NULL; c->start_tail_n = 0; c->start_counter = counter;
+  if (tail && n) { c->start_tail = malloc (n * sizeof (uint16_t)); memcpy (c->start_tail, tail, n * sizeof (uint16_t)); c->start_tail_n = n; }
+}
+void orc_icao_export (const orc_ctx *c, uint32_t *slots) { memcpy (slots, c->icao, sizeof c->icao); }
+void orc_icao_import (orc_ctx *c, const uint32_t *slots) { memcpy (c->icao, slots, sizeof c->icao); }
+/* the overlap the last orc_run_stream left for a following shard */
+static uint16_t g_last_tail[4096]; static uint32_t g_last_tail_n;
+uint32_t orc_last_tail (uint16_t *out) { memcpy (out, g_last_tail, g_last_tail_n * sizeof (uint16_t)); return g_last_tail_n; }
 
 void orc_reset (orc_ctx *c)
 {
@@ -1244,11 +1260,13 @@ int orc_run_stream (orc_ctx *c, const void *iq, size_t nbytes, int format,
   uint16_t *tail = calloc (ov ? ov : 1, sizeof (uint16_t));
   int conv = orc_convert_select (format, filter_dc, compute_power);
   orc_convert_state st;
-  uint64_t counter = 0;
+  uint64_t counter = c->start_counter;
   size_t off = 0;
   int nblocks = 0, eof = 0;
+  int first_block = (int) (c->start_counter / (ASYNC_BUF_SIZE / bps));
 
   if (conv < 0) { free (data); free (tail); return -1; }
+  if (c->start_tail && c->start_tail_n == ov) memcpy (tail, c->start_tail, ov * sizeof (uint16_t));
   orc_convert_state_init (&st, c->sample_rate, filter_dc);
 
   while (!eof) {
@@ -1268,7 +1286,7 @@ int orc_run_stream (orc_ctx *c, const void *iq, size_t nbytes, int format,
     memcpy (tail, data + mb.valid_length - ov, ov * sizeof (uint16_t));
     if (block_crc32) block_crc32[nblocks] = crc32_zlib ((const uint8_t *)(data + ov), nsamp * sizeof (uint16_t));
     if (block_power) block_power[nblocks] = mb.mean_power;
-    c->cur_block = nblocks;
+    c->cur_block = first_block + nblocks;
     switch (which_demod) {
       case 2000: orc_demod_2000 (c, &mb); break;
       case 2400: orc_demod_2400 (c, &mb); if (also_ac) orc_demod_2400_AC (c, &mb); break;
@@ -1278,6 +1296,8 @@ int orc_run_stream (orc_ctx *c, const void *iq, size_t nbytes, int format,
     nblocks++;
     if (max_blocks > 0 && nblocks >= max_blocks) break;
   }
+  g_last_tail_n = ov < 4096 ? ov : 0;
+  memcpy (g_last_tail, tail, g_last_tail_n * sizeof (uint16_t));
   free (data); free (tail);
   return nblocks;
 }

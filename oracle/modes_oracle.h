@@ -136,6 +136,12 @@ int orc_run_stream (orc_ctx *c, const void *iq, size_t nbytes, int format,
                     int filter_dc, int compute_power, int which_demod, int also_ac,
                     uint32_t *block_crc32, int max_blocks, double *block_power);
 
+/* sharded runs (test support): where the next orc_run_stream starts, ICAO cache hand-over, the overlap it leaves */
+void     orc_stream_start (orc_ctx *c, uint64_t counter, const uint16_t *tail, uint32_t n);
+void     orc_icao_export (const orc_ctx *c, uint32_t *slots1024);
+void     orc_icao_import (orc_ctx *c, const uint32_t *slots1024);
+uint32_t orc_last_tail (uint16_t *out);
+
 size_t          orc_num_messages (const orc_ctx *c);
 const orc_msg  *orc_messages (const orc_ctx *c);
 void            orc_get_stats (const orc_ctx *c, orc_stats *out);

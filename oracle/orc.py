@@ -90,6 +90,11 @@ def lib():
         L.orc_slice_2000.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.orc_run_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_stream_start.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]
+        L.orc_icao_export.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_icao_import.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_last_tail.argtypes = [C.c_void_p]
+        L.orc_last_tail.restype = C.c_uint32
         L.orc_num_messages.restype = C.c_size_t
         L.orc_num_messages.argtypes = [C.c_void_p]
         L.orc_messages.restype = C.c_void_p
@@ -186,6 +191,28 @@ class Oracle:
         self.last_block_crc32 = crcs[:n]
         self.last_block_power = powers[:n]
         return n
+
+    # ---- sharded runs (test support) ----
+    def stream_start(self, counter, tail=None):
+        if tail is None:
+            self.L.orc_stream_start(self.h, counter, None, 0)
+        else:
+            t = np.ascontiguousarray(tail, dtype=np.uint16)
+            self.L.orc_stream_start(self.h, counter, _ptr(t), len(t))
+
+    def icao_export(self):
+        a = np.zeros(1024, dtype=np.uint32)
+        self.L.orc_icao_export(self.h, _ptr(a))
+        return a
+
+    def icao_import(self, slots):
+        a = np.ascontiguousarray(slots, dtype=np.uint32)
+        self.L.orc_icao_import(self.h, _ptr(a))
+
+    def last_tail(self):
+        a = np.zeros(4096, dtype=np.uint16)
+        n = self.L.orc_last_tail(_ptr(a))
+        return a[:n].copy()
 
     def messages(self):
         n = self.L.orc_num_messages(self.h)
