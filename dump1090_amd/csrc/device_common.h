@@ -25,13 +25,29 @@ using u64 = unsigned long long;
 // converters, one sample
 // ------------------------------------------------------------------------------------------
 
-// ref: src/convert.c:254-292
+// ref: src/convert.c:254-292.  The reference branches four ways on (I < Q, I < threshold(Q)); the four linear forms
+// pair up under swapping I and Q, so with small = min, big = max one select on (I < Q) == (I < t) picks the pair:
+//   mag = ((sel ? 12868 : 36646) * small + (sel ? 64692 : 54842) * big) >> 16
+__device__ __forceinline__ uint32_t mag_sc16_abs (uint32_t I, uint32_t Q)      // I, Q = |i16|, |q16| in 0..32768
+{
+  const bool lt = I < Q;
+  const uint32_t small = lt ? I : Q, big = lt ? Q : I;
+  const uint32_t t = __umul24 (lt ? 106u : 618u, Q) >> 8;
+  const bool sel = lt == (I < t);
+  return (__umul24 (sel ? 12868u : 36646u, small) + __umul24 (sel ? 64692u : 54842u, big)) >> 16;
+}
 __device__ __forceinline__ uint16_t mag_sc16_int (int i16, int q16)
 {
-  uint32_t I = uint32_t (i16 < 0 ? -i16 : i16), Q = uint32_t (q16 < 0 ? -q16 : q16), mag;
-  if (I < Q) mag = (I < ((106u * Q) >> 8)) ? (12868u * I + 64692u * Q) >> 16 : (36646u * I + 54842u * Q) >> 16;
-  else       mag = (I < ((618u * Q) >> 8)) ? (54842u * I + 36646u * Q) >> 16 : (64692u * I + 12868u * Q) >> 16;
-  return uint16_t (mag);
+  return uint16_t (mag_sc16_abs (uint32_t (i16 < 0 ? -i16 : i16), uint32_t (q16 < 0 ? -q16 : q16)));
+}
+// one IQ pair as it lies in memory (I in the low half): |.| of both halves with two packed operations
+typedef short short2v __attribute__ ((ext_vector_type (2)));
+__device__ __forceinline__ uint32_t mag_sc16_word (uint32_t d)
+{
+  const short2v v = __builtin_bit_cast (short2v, d);
+  const short2v a = __builtin_elementwise_max (v, short2v (-v));      // -32768 stays 0x8000 = 32768 unsigned
+  const uint32_t u = __builtin_bit_cast (uint32_t, a);
+  return mag_sc16_abs (u & 0xFFFFu, u >> 16);
 }
 
 // ref: src/convert.c:142-147 -- the tail shared by the three float converters, DC block already applied
@@ -186,7 +202,7 @@ __device__ __forceinline__ uint4 convert_raw8 (const uint16_t *lut, const uint32
       out[k] = mag_from_float (c_uc8_float[iqp & 0xFF], c_uc8_float[(iqp >> 8) & 0xFF], nullptr);
     } else {
       const int I = int (int16_t (d[k] & 0xFFFF)), Q = int (int16_t (d[k] >> 16));
-      if (CONV == kConvSc16Int) out[k] = mag_sc16_int (I, Q);
+      if (CONV == kConvSc16Int) out[k] = uint16_t (mag_sc16_word (d[k]));
       else {
         const float sc = CONV == kConvSc16Generic ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
         out[k] = mag_from_float (float (I) * sc, float (Q) * sc, nullptr);
