@@ -281,6 +281,75 @@ __device__ __forceinline__ void stage_tile (uint16_t *tile, const uint16_t *lut,
   }
 }
 
+// Position-aligned staging: tile[x] = magnitude of sample s0 + x for x in [0, kCount).  `tile` is 16-byte aligned with
+// kTileLead uint16 of slack in front (a chunk that straddles s0 spills there) and room for 8 * ((kCount + 14) / 8)
+// entries behind.  Global loads stay 8-sample aligned; the realignment happens in the LDS store.
+constexpr int kTileLead = 8;
+template <int kCount> struct TileChunks { static constexpr int n = (kCount + 14) / 8; };
+
+template <int CONV>
+__device__ __forceinline__ uint16_t mag_of_sample (const uint16_t *lut, const ScanParams &p, long long n, long long N)
+{
+  if (n < 0) return (p.halo && n + (long long) p.ov >= 0) ? p.halo[n + (long long) p.ov] : uint16_t (0);
+  if (n >= N) return 0;
+  if (CONV == kConvMagU16) return reinterpret_cast<const uint16_t *> (p.iq)[n];
+  if (CONV == kConvUc8Lut || CONV == kConvUc8LutPower) {
+    const uint64_t blk = uint64_t (n) / p.block_samples, i = uint64_t (n) % p.block_samples;
+    return lut[p.iq[blk * 2 * p.block_samples + i]];
+  }
+  if (CONV == kConvUc8Generic) return mag_from_float (c_uc8_float[p.iq[2 * n]], c_uc8_float[p.iq[2 * n + 1]], nullptr);
+  const int16_t *s = reinterpret_cast<const int16_t *> (p.iq) + 2 * n;
+  if (CONV == kConvSc16Int) return mag_sc16_int (s[0], s[1]);
+  const float sc = CONV == kConvSc16Generic ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
+  return mag_from_float (float (s[0]) * sc, float (s[1]) * sc, nullptr);
+}
+
+template <int CONV, int kCount>
+__device__ __forceinline__ void stage_tile_pos (uint16_t *tile, const uint16_t *lut, const ScanParams &p, long long s0, int lane)
+{
+  constexpr int kChunks = TileChunks<kCount>::n;
+  constexpr int kIters = (kChunks + 63) / 64;
+  constexpr int NW = RawWords<CONV>::n;
+  const long long N = (long long) (CONV == kConvMagU16 ? p.navail : p.nsamples);
+  const long long a_lo = (s0 >= 0 ? s0 : s0 - 7) / 8 * 8;
+  const int shift = int (s0 - a_lo);                           // 0..7, the same for every wave of a launch
+  if (a_lo >= 0 && a_lo + 8 * kChunks <= N) {
+    uint32_t raw[kIters][NW];
+#pragma unroll
+    for (int it = 0; it < kIters; it++) {
+      const int ch = it * 64 + lane;
+      if (ch < kChunks) load_raw8<CONV> (p, a_lo + 8 * ch, raw[it]);
+    }
+#pragma unroll
+    for (int it = 0; it < kIters; it++) {
+      const int ch = it * 64 + lane;
+      if (ch < kChunks) {
+        const uint4 pk = convert_raw8<CONV> (lut, raw[it]);
+        uint16_t *dst = tile + 8 * ch - shift;
+        if (shift == 0) *reinterpret_cast<uint4 *> (dst) = pk;
+        else if (!(shift & 1)) {
+          uint32_t *d32 = reinterpret_cast<uint32_t *> (dst);
+          d32[0] = pk.x; d32[1] = pk.y; d32[2] = pk.z; d32[3] = pk.w;
+        } else {
+          dst[0] = uint16_t (pk.x); dst[1] = uint16_t (pk.x >> 16); dst[2] = uint16_t (pk.y); dst[3] = uint16_t (pk.y >> 16);
+          dst[4] = uint16_t (pk.z); dst[5] = uint16_t (pk.z >> 16); dst[6] = uint16_t (pk.w); dst[7] = uint16_t (pk.w >> 16);
+        }
+      }
+    }
+    return;
+  }
+  // first / last strips of the shard: per-sample bounds
+  for (int c = lane * 8; c < (kCount + 7) / 8 * 8; c += 64 * 8) {
+    uint16_t out[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) out[k] = mag_of_sample<CONV> (lut, p, s0 + c + k, N);
+    uint4 pk;
+    pk.x = out[0] | (uint32_t (out[1]) << 16); pk.y = out[2] | (uint32_t (out[3]) << 16);
+    pk.z = out[4] | (uint32_t (out[5]) << 16); pk.w = out[6] | (uint32_t (out[7]) << 16);
+    *reinterpret_cast<uint4 *> (&tile[c]) = pk;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // one magnitude of the virtual stream V[x] (x = scan position domain), any converter, slow path
 // ------------------------------------------------------------------------------------------

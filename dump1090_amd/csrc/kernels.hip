@@ -18,267 +18,315 @@ namespace modes {
 
 
 // LDS per wave
-struct WaveLds {
-  uint16_t tile[kStrip + kLook2400 + kTilePad];   // magnitudes V[P0 - shift ...]
-  uint16_t q1[kQ1Cap];                            // off | pattern << 12
-  uint32_t q2[kQ2Cap];                              // off | (t-4) << 12 | df << 16
-  uint16_t lut[256];                              // as-written uc8 table
-  uint32_t sb[kLongBits];
-  u64      vp[kWords];                                // valid-preamble bit per position of the strip
+constexpr int kTileN = 8 * TileChunks<kStrip + kLook2400>::n;
+constexpr int kQ1Seg = 256;
+template <bool PE> struct WaveLds {
+  alignas (16) uint16_t tile[kTileLead + kTileN];   // tile[kTileLead + x] = V[P0 + x]
+  uint16_t q1[kQ1Seg];                              // off | pattern << 12, kQ1Seg candidates at a time
+  uint32_t q2[PE ? 5 * 64 : 64];                    // off | (t-4) << 12 | df << 16, one stage-C batch at a time
+  uint32_t vp[kStrip / 32];                         // valid-preamble bit per position of the strip
 };
 
 constexpr int kWavesPerBlock = 4;
 
+__device__ __forceinline__ uint32_t alignbit (uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit (hi, lo, sh); }
+
+// One data bit of the 2.4 MS/s slicers, weight folded in, on the differences e[j] = d[j] - d[j+1]:
+//   5a-3b-2c = 5e0+2e1, 4a-b-3c = 4e0+3e1, 3a+b-4c = 3e0+4e1, 2a+3b-5c = 2e0+5e1, a+5b-5c-d = e0+6e1+e2
+// (ref: src/demod-2400.c:32-55); F = fifths of a sample after d[0].
+template <int F>
+__device__ __forceinline__ int wslice (const int *e)
+{
+  constexpr int i = F / 5, r = F % 5, w = corr_weight<r> ();
+  int v = __mul24 (e[i], w * (5 - r)) + __mul24 (e[i + 1], w * (2 + r));
+  if (r == 4) v += __mul24 (e[i + 2], w);
+  return v;
+}
+// correlate_check for start phase T (ref: src/demod-2400.c:86-129): returns the score, shifts the five sliced bits into F5
+template <int T>
+__device__ __forceinline__ int phase_score (const int *e, uint32_t &F5)
+{
+  const int a = wslice<T> (e), b = wslice<T + 12> (e), c = wslice<T + 24> (e), d = wslice<T + 36> (e), g = wslice<T + 48> (e);
+  const int na = -a, nb = -b, nc = -c, nd = -d, ng = -g;
+  F5 = alignbit (F5, uint32_t (na), 31); F5 = alignbit (F5, uint32_t (nb), 31); F5 = alignbit (F5, uint32_t (nc), 31);
+  F5 = alignbit (F5, uint32_t (nd), 31); F5 = alignbit (F5, uint32_t (ng), 31);
+  return max (a, na) + max (b, nb) + max (c, nc) + max (d, nd) + max (g, ng);
+}
+
+// one data bit that starts f fifths of a sample after m[0]: > 0 means 1 (ref: src/demod-2400.c:32-55, 339-412)
+__device__ __forceinline__ int slice_at (const uint16_t *m, int f)
+{
+  const int i = (f * 0xCCCD) >> 18, ph = f - 5 * i;
+  const int m0 = m[i], m1 = m[i + 1], m2 = m[i + 2], m3 = m[i + 3];
+  const int e0 = m0 - m1, e1 = m1 - m2, e2 = m2 - m3;
+  return __mul24 (e0, 5 - ph) + __mul24 (e1, 2 + ph) + __mul24 (e2, ph >> 2);
+}
+
+// XOR over the 64 lanes, result valid in lane 63
+__device__ __forceinline__ uint32_t wave_xor_to63 (uint32_t v)
+{
+  v = row_xor (v);
+  v ^= dpp_mov<0x142, 0xA, false> (v);
+  v ^= dpp_mov<0x143, 0xC, false> (v);
+  return v;
+}
 
 // ------------------------------------------------------------------------------------------
 // the scan kernel
 // ------------------------------------------------------------------------------------------
-template <int CONV>
+template <int CONV, bool PE>
 __global__ __launch_bounds__ (64 * kWavesPerBlock)
 void scan2400_kernel (const ScanParams p)
 {
-  __shared__ WaveLds lds[kWavesPerBlock];
+  constexpr bool kLut = CONV == kConvUc8Lut || CONV == kConvUc8LutPower;
+  __shared__ WaveLds<PE> lds[kWavesPerBlock];
+  __shared__ uint16_t s_lut[kLut ? 256 : 1];        // as-written uc8 table
   const int lane = lane_id ();
   const int wv = threadIdx.x >> 6;
-  WaveLds &w = lds[wv];
+  WaveLds<PE> &w = lds[wv];
+  if (kLut) {
+    s_lut[threadIdx.x] = p.lut256[threadIdx.x];
+    __syncthreads ();
+  }
   const uint32_t strip = blockIdx.x * kWavesPerBlock + wv;
   if (strip >= p.nstrips) return;
+  w.vp[lane] = 0;
 
-  // wave-private tables
-  for (int i = lane; i < 256; i += 64) w.lut[i] = p.lut256 ? p.lut256[i] : uint16_t (0);
-  for (int i = lane; i < kLongBits; i += 64) w.sb[i] = c_single_bit[i];
-  if (lane < kWords) w.vp[lane] = 0;
+  // stage D maps lane -> message bit (lane ^ 7) (+ 64 in the second round): a ballot then holds the message bytes as they
+  // lie in memory.  Single-bit syndromes of those bits for 112-bit and 56-bit CRCs (ref: src/crc.c:35,56-61)
+  const int bl = lane ^ 7;
+  const uint32_t sbL0 = c_single_bit[bl], sbL1 = bl < 48 ? c_single_bit[64 + bl] : 0u, sbS = bl < 56 ? c_single_bit[56 + bl] : 0u;
 
-  // ---- stage A: magnitudes of V[P0 .. P0 + kStrip + kLook2400) into LDS ----
+  // ---- stage A: magnitudes V[P0 .. P0 + kStrip + kLook2400) into LDS ----
   const long long P0 = (long long) strip * kStrip;
-  const long long s0 = P0 - (long long) (CONV == kConvMagU16 ? 0u : p.ov);   // first sample index needed (may be < 0)
-  const long long a_lo = (s0 >= 0 ? s0 : s0 - 15) / 16 * 16;  // floor to a multiple of 16
-  const int shift = int (s0 - a_lo);                          // V[P0 + x] == tile[x + shift]
-  stage_tile<CONV, kStrip + kLook2400 + kTilePad> (w.tile, w.lut, p, a_lo, lane);
+  const long long s0 = P0 - (long long) (CONV == kConvMagU16 ? 0u : p.ov);   // sample index of V[P0] (may be < 0)
+  uint16_t *V = w.tile + kTileLead;
+  stage_tile_pos<CONV, kStrip + kLook2400> (V, s_lut, p, s0, lane);
   __builtin_amdgcn_s_waitcnt (0xc07f);   // lgkmcnt(0): LDS writes of this wave are done (wave-private data)
   __builtin_amdgcn_wave_barrier ();
 
-  const uint16_t *V = w.tile + shift;
   if (p.debug_stop == 1) { if (lane == 0) p.counts[strip] = V[lane]; return; }
 
-  // ---- stage B: LT/GT bit planes; lane l ends up owning word l = positions [64 l, 64 l + 64) ----
-  uint32_t lt_lo = 0, lt_hi = 0, gt_lo = 0, gt_hi = 0;
-  u64 lt_last = 0, gt_last = 0;
-#pragma unroll 3
-  for (int s = 0; s <= kWords; s++) {
-    const int x = 64 * s + lane;
-    const uint32_t a = V[x], b = V[x + 1];
-    const u64 lt = __ballot (a < b), gt = __ballot (a > b);
-    if (s < kWords) {
-      if (lane == s) { lt_lo = uint32_t (lt); lt_hi = uint32_t (lt >> 32); gt_lo = uint32_t (gt); gt_hi = uint32_t (gt >> 32); }
-    } else { lt_last = lt; gt_last = gt; }
+  // ---- stage B: lane l owns positions [32 l, 32 l + 32): LT/GT bit planes from its own 33 samples ----
+  uint32_t LT = 0, GT = 0;
+  {
+    const uint4 *vw = reinterpret_cast<const uint4 *> (V + 32 * lane);
+    const uint4 x0 = vw[0], x1 = vw[1], x2 = vw[2], x3 = vw[3];
+    const uint32_t wd[17] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w,
+                              uint32_t (V[32 * lane + 32]) };
+#pragma unroll
+    for (int k = 31; k >= 0; k--) {
+      const int a = int ((wd[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+      const int b = int ((wd[(k + 1) >> 1] >> (16 * ((k + 1) & 1))) & 0xFFFFu);
+      const int d = a - b;
+      LT = alignbit (LT, uint32_t (d), 31);        // shifts in (a < b)
+      GT = alignbit (GT, uint32_t (-d), 31);       // shifts in (a > b)
+    }
   }
-  const u64 LT = (u64 (lt_hi) << 32) | lt_lo, GT = (u64 (gt_hi) << 32) | gt_lo;
-  u64 LTn = (u64 (uint32_t (__shfl_down (int (lt_hi), 1, 64))) << 32) | uint32_t (__shfl_down (int (lt_lo), 1, 64));
-  u64 GTn = (u64 (uint32_t (__shfl_down (int (gt_hi), 1, 64))) << 32) | uint32_t (__shfl_down (int (gt_lo), 1, 64));
-  if (lane == kWords - 1) { LTn = lt_last; GTn = gt_last; }
-  if (lane >= kWords) { LTn = 0; GTn = 0; }
+  uint32_t LTn = dpp_mov<0x130, 0xF, true> (LT), GTn = dpp_mov<0x130, 0xF, true> (GT);   // wave_shl:1 = lane + 1's word
+  {   // the word behind the strip, for lane 63
+    const uint32_t a = V[kStrip + (lane & 15)], b = V[kStrip + (lane & 15) + 1];
+    const uint32_t l = uint32_t (__ballot (a < b)) & 0xFFFFu, g = uint32_t (__ballot (a > b)) & 0xFFFFu;
+    if (lane == 63) { LTn = l; GTn = g; }
+  }
 
   // peaks P_k = (p[k] < p[k+1] > p[k+2]); the five layouts of ref: src/demod-2400.c:225-282 with the
   // quick check (p0 < p1, p12 > p13) folded in.
-#define LTk(k) funnel (LT, LTn, k)
-#define GTk(k) funnel (GT, GTn, k)
-  const u64 P0m = LT & GTk (1), P2m = LTk (2) & GTk (3), P8m = LTk (8) & GTk (9), P11m = LTk (11) & GTk (12);
-  const u64 P3m = LTk (3) & GTk (4), P9m = LTk (9) & GTk (10);
-  const u64 t389 = P0m & P2m & P8m;
-  const u64 ph3 = t389 & LTk (10) & GTk (12);
-  const u64 ph4 = t389 & P11m;
-  const u64 ph5 = P0m & P11m & LTk (2) & GTk (4) & LTk (8) & GTk (10);
-  const u64 u39b = P3m & P9m & P11m;
-  const u64 ph6 = P0m & u39b;
-  const u64 ph7 = LT & GTk (2) & u39b;
+#define LTk(k) alignbit (LTn, LT, k)
+#define GTk(k) alignbit (GTn, GT, k)
+  const uint32_t P0m = LT & GTk (1), P2m = LTk (2) & GTk (3), P8m = LTk (8) & GTk (9), P11m = LTk (11) & GTk (12);
+  const uint32_t P3m = LTk (3) & GTk (4), P9m = LTk (9) & GTk (10);
+  const uint32_t t389 = P0m & P2m & P8m;
+  const uint32_t ph3 = t389 & LTk (10) & GTk (12);
+  const uint32_t ph4 = t389 & P11m;
+  const uint32_t ph5 = P0m & P11m & LTk (2) & GTk (4) & LTk (8) & GTk (10);
+  const uint32_t u39b = P3m & P9m & P11m;
+  const uint32_t ph6 = P0m & u39b;
+  const uint32_t ph7 = LT & GTk (2) & u39b;
 #undef LTk
 #undef GTk
-  u64 any = ph3 | ph4 | ph5 | ph6 | ph7;
+  uint32_t any = ph3 | ph4 | ph5 | ph6 | ph7;
   {   // positions at or beyond the end of the stream are not scanned (ref: src/demod-2400.c:200)
-    const long long base = P0 + 64ll * lane, N = (long long) p.nsamples;
+    const long long base = P0 + 32ll * lane, N = (long long) p.nsamples;
     if (base >= N) any = 0;
-    else if (base + 64 > N) any &= (~0ull) >> (64 - int (N - base));
+    else if (base + 32 > N) any &= (~0u) >> (32 - int (N - base));
   }
+  // first matching layout wins (else-if chain): code planes of the layout index 0..4
+  const uint32_t n3 = ~ph3, n34 = n3 & ~ph4, n345 = n34 & ~ph5;
+  const uint32_t e6 = ph6 & n345, e7 = any & n345 & ~ph6;
+  const uint32_t c0 = (ph4 & n3) | e6, c1 = (ph5 & n34) | e6, c2 = e7;
 
-  if (p.debug_stop == 2) { if (any == 0x1234567ull) p.counts[strip] = 1; return; }
-  // ---- queue 1: candidate positions in ascending order ----
-  const int mycnt = __popcll (any);
+  if (p.debug_stop == 2) { if (any == 0x1234567u) p.counts[strip] = 1; return; }
+  // ---- candidates in ascending order, kQ1Seg at a time through queue 1 ----
+  const int mycnt = __popc (any);
   const int incl = wave_incl_scan (mycnt, lane);
   const int n1 = __shfl (incl, 63, 64);
-  bool overflow = n1 > kQ1Cap;
-  if (!overflow) {
-    int slot = incl - mycnt;
-    u64 mm = any;
-    while (mm) {
-      const int b = __builtin_ctzll (mm);
-      const u64 bit = 1ull << b;
-      mm &= mm - 1;
-      const int pat = (ph3 & bit) ? 0 : (ph4 & bit) ? 1 : (ph5 & bit) ? 2 : (ph6 & bit) ? 3 : 4;
-      w.q1[slot++] = uint16_t ((64 * lane + b) | (pat << 12));
-    }
-  }
-  __builtin_amdgcn_s_waitcnt (0xc07f);
-  __builtin_amdgcn_wave_barrier ();
-
-  // ---- stage C: amplitude tests + phase pick, one lane per candidate ----
-  int n2 = 0;
-  uint32_t valid_preamble = 0;
-  for (int base = 0; base < n1 && !overflow; base += 64) {
-    const int qi = base + lane;
-    bool pass = false;
-    int off = 0, nent = 0;
-    uint32_t ent[5];
-    if (qi < n1) {
-      const uint32_t e = w.q1[qi];
-      off = e & 0xFFF;
-      const int pat = e >> 12;
-      const uint16_t *pp = V + off;
-      int s[19];
-#pragma unroll
-      for (int k = 0; k < 19; k++) s[k] = pp[k];
-      int high; uint32_t sig, noise;
-      switch (pat) {     // ref: src/demod-2400.c:233-281
-        case 0:  high = (s[1] + s[3] + s[9] + s[11] + s[12]) / 4; sig = s[1] + s[3] + s[9]; noise = s[5] + s[6] + s[7]; break;
-        case 1:  high = (s[1] + s[3] + s[9] + s[12]) / 4; sig = s[1] + s[3] + s[9] + s[12]; noise = s[5] + s[6] + s[7] + s[8]; break;
-        case 2:  high = (s[1] + s[3] + s[4] + s[9] + s[10] + s[12]) / 4; sig = s[1] + s[12]; noise = s[6] + s[7]; break;
-        case 3:  high = (s[1] + s[4] + s[10] + s[12]) / 4; sig = s[1] + s[4] + s[10] + s[12]; noise = s[5] + s[6] + s[7] + s[8]; break;
-        default: high = (s[1] + s[2] + s[4] + s[10] + s[12]) / 4; sig = s[4] + s[10] + s[12]; noise = s[6] + s[7] + s[8]; break;
-      }
-      pass = !(sig * 2 < 3 * noise) &&                                                  // ref: :292
-             s[5] < high && s[6] < high && s[7] < high && s[8] < high && s[14] < high &&
-             s[15] < high && s[16] < high && s[17] < high && s[18] < high;              // ref: :297-308
-      if (pass) {
-        int d[15];
-#pragma unroll
-        for (int k = 0; k < 15; k++) d[k] = pp[19 + k];
-        int fb[5], cv[5];
-        cv[0] = check_phase<4> (d, &fb[0]); cv[1] = check_phase<5> (d, &fb[1]); cv[2] = check_phase<6> (d, &fb[2]);
-        cv[3] = check_phase<7> (d, &fb[3]); cv[4] = check_phase<8> (d, &fb[4]);
-        if (p.phase_enhance) {                                                          // ref: :310-314
-#pragma unroll
-          for (int t = 0; t < 5; t++)
-            if (slice_bytes_for_df (fb[t])) ent[nent++] = uint32_t (off) | (uint32_t (t) << 12) | (uint32_t (fb[t]) << 16);
-        } else {                                                                        // ref: :134-179, 319-323
-          int best = -1, bestval = d[0] + d[1] + d[2] + d[3] + d[4] + d[5], df = 0;
-#pragma unroll
-          for (int t = 0; t < 5; t++) if (cv[t] > bestval) { bestval = cv[t]; best = t; df = fb[t]; }
-          pass = best >= 0;
-          if (pass && slice_bytes_for_df (df)) ent[nent++] = uint32_t (off) | (uint32_t (best) << 12) | (uint32_t (df) << 16);
-        }
-      }
-    }
-    valid_preamble += __popcll (__ballot (pass));                                       // ref: :326
-    if (pass) atomicOr (&w.vp[off >> 6], 1ull << (off & 63));
-    const int inc = wave_incl_scan (nent, lane);
-    const int tot = __shfl (inc, 63, 64);
-    if (n2 + tot > kQ2Cap) { overflow = true; break; }
-    int slot = n2 + inc - nent;
-    for (int k = 0; k < nent; k++) w.q2[slot + k] = ent[k];
-    n2 += tot;
-  }
-  __builtin_amdgcn_s_waitcnt (0xc07f);
-  __builtin_amdgcn_wave_barrier ();
-
-  if (p.debug_stop == 3) { if (lane == 0) p.counts[strip] = n2 + valid_preamble; return; }
-  // ---- stage D: 56/112-bit slicing + CRC; 16 lanes per candidate, lane r of a row slices byte r ----
-  uint32_t nrec = 0;
+  bool overflow = false;
+  uint32_t valid_preamble = 0, nrec = 0;
   Record *out = p.records + size_t (strip) * p.cap;
-  const int row = lane >> 4, r = lane & 15;
-  for (int base = 0; base < n2 && !overflow; base += 4) {
-    const int ci = base + row;
-    const bool act = ci < n2;
-    const uint32_t e = act ? w.q2[ci] : 0u;
-    const int off = e & 0xFFF, t = 4 + int ((e >> 12) & 7), df = int (e >> 16);
-    const int nbytes = act ? slice_bytes_for_df (df) : 0;   // 7 or 14 (ref: src/demod-2400.c:416-435)
-    const int ncrc = msg_bits_for_df (df);                  // bits the score's CRC runs over
-    const uint16_t *m = V + off + 19;
-    uint32_t byte = 0;
-    if (r < nbytes) {
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const int f = t + 12 * (8 * r + k);
-        const int i = (f * 0xCCCD) >> 18, ph = f - 5 * i;
-        const int a0 = m[i], a1 = m[i + 1], a2 = m[i + 2], a3 = m[i + 3];
-        const int w2 = ph < 3 ? 2 + ph : 5;
-        const int v = (5 - ph) * a0 + (2 * ph - 3) * a1 - w2 * a2 - (ph == 4 ? a3 : 0);
-        byte = (byte << 1) | uint32_t (v > 0);
-      }
-    }
-    // syndrome = XOR of the single-bit syndromes of the set bits (the CRC is linear, ref: src/crc.c:56-61)
-    const bool in_crc = 8 * r < ncrc;
-    uint32_t x = 0;
-    if (in_crc && byte) {
-      const uint32_t *sb = &w.sb[8 * r + (kLongBits - ncrc)];
-#pragma unroll
-      for (int k = 0; k < 8; k++) if ((byte >> (7 - k)) & 1) x ^= sb[k];
-    }
-    const uint32_t syn = row_xor (x);
-    const uint32_t live = row_or (in_crc ? byte : 0u);       // all-zero message -> -2 (ref: src/dump1090.c:3295)
-    const uint32_t part = byte << (8 * (r & 3));
-    const uint32_t w0 = row_or ((r >> 2) == 0 ? part : 0u), w1 = row_or ((r >> 2) == 1 ? part : 0u);
-    const uint32_t w2 = row_or ((r >> 2) == 2 ? part : 0u), w3 = row_or ((r >> 2) == 3 ? part : 0u);
+  // per-lane results of stage D1 (lane = candidate of the batch)
+  uint32_t r_m0lo = 0, r_m0hi = 0, r_m1lo = 0, r_m1hi = 0, r_syn = 0;
 
-    bool keep = act && live != 0;
-    int cls, nerr = 0, b0 = 0, b1 = 0;
-    const bool es = df == 17 || df == 18, acq = df == 11;
-    if (es || acq) {
-      cls = acq ? kClsDF11 : kClsES;
-      const uint32_t key = acq ? (syn & 0xFFFF80u) : syn;
-      const bool shortt = ncrc == kShortBits;
-      const ErrEntry *tab = shortt ? p.short_tab : p.long_tab;
-      const int tn = shortt ? p.short_n : p.long_n;
-      bool need = keep && key != 0;
-      if (need) {                                           // 64 Kbit filter in front of the table
-        const uint32_t h = (key ^ (key >> 12)) & 0xFFFF;
-        const uint32_t *bloom = shortt ? p.bloom_short : p.bloom_long;
-        need = tn > 0 && ((bloom[h >> 5] >> (h & 31)) & 1);
-        if (!need) keep = false;                            // uncorrectable (ref: src/dump1090.c:3315,3343)
+  for (int seg = 0; seg < n1 && !overflow; seg += kQ1Seg) {
+    {
+      int slot = incl - mycnt - seg;
+      uint32_t mm = any;
+      while (mm) {
+        const int b = __builtin_ctz (mm);
+        mm &= mm - 1;
+        const uint32_t pat = ((c0 >> b) & 1u) | (((c1 >> b) & 1u) << 1) | (((c2 >> b) & 1u) << 2);
+        if (uint32_t (slot) < uint32_t (kQ1Seg)) w.q1[slot] = uint16_t ((32 * lane + b) | (pat << 12));
+        slot++;
       }
-      if (__ballot (need)) {
-        int lo = 0, len = need ? tn : 0;
+    }
+    __builtin_amdgcn_s_waitcnt (0xc07f);
+    __builtin_amdgcn_wave_barrier ();
+    const int nseg = min (n1 - seg, kQ1Seg);
+
+    for (int base = 0; base < nseg && !overflow; base += 64) {
+      // ---- stage C: amplitude tests + phase pick, one lane per candidate ----
+      const int qi = base + lane;
+      bool pass = false;
+      int off = 0, nent = 0;
+      uint32_t ent[PE ? 5 : 1];
+      if (qi < nseg) {
+        const uint32_t qe = w.q1[qi];
+        off = qe & 0xFFF;
+        const int pat = qe >> 12;
+        const uint16_t *pp = V + off;
+        int s[19];
 #pragma unroll
-        for (int level = 0; level < 3; level++) {           // 16-ary search, tables hold <= 4096 entries
-          const int step = len > 16 ? (len + 15) >> 4 : 1;
-          const int idx = lo + r * step;
-          const bool le = r * step < len && tab[idx].syndrome <= key;
-          const uint32_t rowbits = uint32_t (__ballot (le) >> (16 * row)) & 0xFFFFu;
-          if (rowbits == 0) len = 0;
-          else {
-            const int seg = 31 - __builtin_clz (rowbits);
-            lo += seg * step;
-            len = min (step, len - seg * step);
+        for (int k = 0; k < 19; k++) s[k] = pp[k];
+        // ref: src/demod-2400.c:233-281; which samples enter high / base_signal / base_noise, by layout index
+        const int s39 = s[3] + s[9], s410 = s[4] + s[10];
+        const int hsum = s[1] + s[12] + (pat <= 2 ? s39 : 0) + (pat >= 2 ? s410 : 0) + (pat == 4 ? s[2] : 0) + (pat == 0 ? s[11] : 0);
+        const int high = hsum >> 2;
+        const uint32_t sig = uint32_t ((pat == 4 ? 0 : s[1]) + (pat <= 1 ? s39 : 0) + (pat >= 3 ? s410 : 0) + (pat == 0 ? 0 : s[12]));
+        const uint32_t noise = uint32_t (s[6] + s[7] + ((pat == 2 || pat == 4) ? 0 : s[5]) + ((pat == 0 || pat == 2) ? 0 : s[8]));
+        const int quiet = max (max (max (s[5], s[6]), max (s[7], s[8])), max (max (max (s[14], s[15]), max (s[16], s[17])), s[18]));
+        pass = !(sig * 2 < 3 * noise) && quiet < high;                                    // ref: :292, :297-308
+        if (pass) {
+          int e[14], thr;
+          {
+            int d[15];
+#pragma unroll
+            for (int k = 0; k < 15; k++) d[k] = pp[19 + k];
+#pragma unroll
+            for (int k = 0; k < 14; k++) e[k] = d[k] - d[k + 1];
+            thr = d[0] + d[1] + d[2] + d[3] + d[4] + d[5];       // threshold of best_phase (ref: :137)
+          }
+          uint32_t F5 = 0;                              // five sliced bits per start phase, phase 4 in bits 24..20
+          const int cv0 = phase_score<4> (e, F5), cv1 = phase_score<5> (e, F5), cv2 = phase_score<6> (e, F5),
+                    cv3 = phase_score<7> (e, F5), cv4 = phase_score<8> (e, F5);
+          if (PE) {                                                                       // ref: :310-314
+#pragma unroll
+            for (int t = 0; t < 5; t++) {
+              const int df = int ((F5 >> (5 * (4 - t))) & 31u);
+              if (slice_bytes_for_df (df)) ent[nent++] = uint32_t (off) | (uint32_t (t) << 12) | (uint32_t (df) << 16);
+            }
+          } else {                                                                        // ref: :134-179, 319-323
+            // strict > against the running best: the earliest phase holding the maximum wins
+            const int key = max (max (max ((cv0 << 3) | 4, (cv1 << 3) | 3), max ((cv2 << 3) | 2, (cv3 << 3) | 1)), cv4 << 3);
+            pass = (key >> 3) > thr;
+            const int sh = key & 7;                    // 4 - phase index
+            const int df = int ((F5 >> (5 * sh)) & 31u);
+            if (pass && slice_bytes_for_df (df)) ent[nent++] = uint32_t (off) | (uint32_t (4 - sh) << 12) | (uint32_t (df) << 16);
           }
         }
-        if (need) {
-          ErrEntry te = { 0, 0, 0, 0, 0 };
-          if (len > 0) te = tab[lo];
-          if (len > 0 && te.syndrome == key && !(acq && te.nerr > 1)) { nerr = te.nerr; b0 = te.bit0; b1 = te.bit1; }
-          else keep = false;                                // ref: src/dump1090.c:3315,3322,3343
-        }
       }
-    } else
-      cls = (df == 20 || df == 21) ? kClsAP2 : kClsAP;
+      valid_preamble += __popcll (__ballot (pass));                                       // ref: :326
+      if (pass) atomicOr (&w.vp[off >> 5], 1u << (off & 31));
+      const int inc = wave_incl_scan (nent, lane);
+      const int n2 = __shfl (inc, 63, 64);                 // <= kQ2Cap by construction
+      {
+        const int slot = inc - nent;
+        for (int k = 0; k < nent; k++) w.q2[slot + k] = ent[k];
+      }
+      __builtin_amdgcn_s_waitcnt (0xc07f);
+      __builtin_amdgcn_wave_barrier ();
+      if (p.debug_stop == 3) continue;
 
-    const u64 kept = __ballot (keep && r == 0);
-    const uint32_t slot = nrec + uint32_t (__popcll (kept & ((1ull << lane) - 1)));
-    const uint32_t total = nrec + uint32_t (__popcll (kept));
-    if (total > p.cap) { overflow = true; break; }
-    if (keep && r == 0 && p.write_records) {
-      // Record layout: off,phase,df | cls,nerr,bit0,bit1 | crc | msg[0..13] | flags,pad
-      uint4 lo4, hi4;
-      lo4.x = uint32_t (off) | (uint32_t (t) << 16) | (uint32_t (df) << 24);
-      lo4.y = uint32_t (cls) | (uint32_t (uint8_t (nerr)) << 8) | (uint32_t (uint8_t (b0)) << 16) | (uint32_t (uint8_t (b1)) << 24);
-      lo4.z = syn;
-      lo4.w = w0;
-      hi4.x = w1; hi4.y = w2; hi4.z = w3 & 0xFFFF; hi4.w = 0;
-      uint4 *dst = reinterpret_cast<uint4 *> (out + slot);
-      dst[0] = lo4; dst[1] = hi4;
+      for (int b2 = 0; b2 < n2 && !overflow; b2 += 64) {
+        const int nq = min (n2 - b2, 64);
+        // ---- stage D1: 56/112-bit slicing + CRC syndrome, one candidate at a time, one lane per message bit ----
+        for (int ci = 0; ci < nq; ci++) {
+          const uint32_t qe = uint32_t (__builtin_amdgcn_readfirstlane (int (w.q2[b2 + ci])));
+          const int coff = qe & 0xFFF, t = 4 + int ((qe >> 12) & 7), df = int (qe >> 16);
+          const bool longmsg = slice_bytes_for_df (df) == kLongBytes;   // 14 bytes sliced, else 7 (ref: src/demod-2400.c:416-435)
+          const bool longcrc = msg_bits_for_df (df) == kLongBits;       // bits the score's CRC runs over
+          const uint16_t *m = V + coff + 19;
+          // syndrome = XOR of the single-bit syndromes of the set bits (the CRC is linear, ref: src/crc.c:56-61)
+          const bool bit0 = slice_at (m, t + 12 * bl) > 0;
+          u64 m0 = __ballot (bit0), m1 = 0;
+          uint32_t x = bit0 ? (longcrc ? sbL0 : sbS) : 0u;
+          if (longmsg) {
+            const bool bit1 = bl < 48 && slice_at (m, t + 12 * (64 + bl)) > 0;
+            m1 = __ballot (bit1);
+            if (longcrc) x ^= bit1 ? sbL1 : 0u;
+          } else m0 &= (1ull << 56) - 1;
+          const uint32_t syn = uint32_t (__builtin_amdgcn_readlane (int (wave_xor_to63 (x)), 63));
+          if (lane == ci) { r_m0lo = uint32_t (m0); r_m0hi = uint32_t (m0 >> 32); r_m1lo = uint32_t (m1); r_m1hi = uint32_t (m1 >> 32); r_syn = syn; }
+        }
+        // ---- stage D2: classes, error-table diagnosis, records; one lane per candidate ----
+        const bool act = lane < nq;
+        const uint32_t qe = act ? w.q2[b2 + lane] : 0u;
+        const int coff = qe & 0xFFF, t = 4 + int ((qe >> 12) & 7), df = int (qe >> 16);
+        const bool longcrc = msg_bits_for_df (df) == kLongBits;
+        const uint32_t syn = r_syn;
+        const u64 m0 = (u64 (r_m0hi) << 32) | r_m0lo, m1 = (u64 (r_m1hi) << 32) | r_m1lo;
+        const u64 crc_bits = longcrc ? (m0 | m1) : (m0 & ((1ull << 56) - 1));
+        bool keep = act && crc_bits != 0;                               // all-zero message -> -2 (ref: src/dump1090.c:3295)
+        int cls, nerr = 0, b0 = 0, b1 = 0;
+        const bool es = df == 17 || df == 18, acq = df == 11;
+        const uint32_t key = acq ? (syn & 0xFFFF80u) : syn;
+        const ErrEntry *tab = longcrc ? p.long_tab : p.short_tab;
+        const int tn = longcrc ? p.long_n : p.short_n;
+        bool need = keep && (es || acq) && key != 0;
+        if (es || acq) cls = acq ? kClsDF11 : kClsES;
+        else           cls = (df == 20 || df == 21) ? kClsAP2 : kClsAP;
+        if (need) {                                                     // 64 Kbit filter in front of the table
+          const uint32_t h = (key ^ (key >> 12)) & 0xFFFF;
+          const uint32_t *bloom = longcrc ? p.bloom_long : p.bloom_short;
+          need = tn > 0 && ((bloom[h >> 5] >> (h & 31)) & 1);
+          if (!need) keep = false;                                      // uncorrectable (ref: src/dump1090.c:3315,3343)
+        }
+        for (u64 nm = __ballot (need); nm; nm &= nm - 1) {              // rare: wave-cooperative table search
+          const int l = __builtin_ctzll (nm);
+          const uint32_t lkey = uint32_t (__builtin_amdgcn_readlane (int (key), l));
+          const bool llong = (__ballot (longcrc) >> l) & 1;
+          const ErrEntry *ltab = llong ? p.long_tab : p.short_tab;
+          const int idx = table_find (ltab, llong ? p.long_n : p.short_n, lkey, lane);
+          if (lane == l) {
+            if (idx >= 0) {
+              const ErrEntry te = ltab[idx];
+              if (acq && te.nerr > 1) keep = false;                     // ref: src/dump1090.c:3322
+              else { nerr = te.nerr; b0 = te.bit0; b1 = te.bit1; }
+            } else keep = false;
+          }
+        }
+        (void) tab;
+        const u64 kept = __ballot (keep);
+        const uint32_t slot = nrec + uint32_t (__popcll (kept & ((1ull << lane) - 1)));
+        const uint32_t total = nrec + uint32_t (__popcll (kept));
+        if (total > p.cap) { overflow = true; break; }
+        if (keep && p.write_records) {
+          // Record layout: off,phase,df | cls,nerr,bit0,bit1 | crc | msg[0..13] | flags,pad
+          uint4 lo4, hi4;
+          lo4.x = uint32_t (coff) | (uint32_t (t) << 16) | (uint32_t (df) << 24);
+          lo4.y = uint32_t (cls) | (uint32_t (uint8_t (nerr)) << 8) | (uint32_t (uint8_t (b0)) << 16) | (uint32_t (uint8_t (b1)) << 24);
+          lo4.z = syn;
+          lo4.w = r_m0lo;
+          hi4.x = r_m0hi; hi4.y = r_m1lo; hi4.z = r_m1hi & 0xFFFFu; hi4.w = 0;
+          uint4 *dst = reinterpret_cast<uint4 *> (out + slot);
+          dst[0] = lo4; dst[1] = hi4;
+        }
+        nrec = total;
+      }
     }
-    nrec = total;
   }
+  if (p.debug_stop == 3) { if (lane == 0) p.counts[strip] = valid_preamble; return; }
 
-  if (p.vp_bitmap && lane < kWords) p.vp_bitmap[size_t (strip) * kWords + lane] = w.vp[lane];
+  if (p.vp_bitmap) reinterpret_cast<uint32_t *> (p.vp_bitmap)[size_t (strip) * (kStrip / 32) + lane] = w.vp[lane];
   if (lane == 0) {      // per-strip results only: no contended atomics
     p.counts[strip] = overflow ? 0xFFFFFFFFu : nrec;
     p.vp_counts[strip] = valid_preamble;
@@ -940,16 +988,21 @@ hipError_t launch_scan2400 (const ScanParams &p, hipStream_t stream)
 {
   const dim3 grid ((p.nstrips + kWavesPerBlock - 1) / kWavesPerBlock), block (64 * kWavesPerBlock);
   if (p.nstrips == 0) return hipSuccess;
+#define SCAN(C)                                                                                    \
+  do {                                                                                             \
+    if (p.phase_enhance) hipLaunchKernelGGL ((scan2400_kernel<C, true>), grid, block, 0, stream, p);  \
+    else                 hipLaunchKernelGGL ((scan2400_kernel<C, false>), grid, block, 0, stream, p); \
+  } while (0)
   switch (p.conv) {
-    case kConvUc8Lut: case kConvUc8LutPower:
-      hipLaunchKernelGGL (scan2400_kernel<kConvUc8Lut>, grid, block, 0, stream, p); break;
-    case kConvUc8Generic:     hipLaunchKernelGGL (scan2400_kernel<kConvUc8Generic>, grid, block, 0, stream, p); break;
-    case kConvSc16Int:        hipLaunchKernelGGL (scan2400_kernel<kConvSc16Int>, grid, block, 0, stream, p); break;
-    case kConvSc16Generic:    hipLaunchKernelGGL (scan2400_kernel<kConvSc16Generic>, grid, block, 0, stream, p); break;
-    case kConvSc16Q11Generic: hipLaunchKernelGGL (scan2400_kernel<kConvSc16Q11Generic>, grid, block, 0, stream, p); break;
-    case kConvMagU16:         hipLaunchKernelGGL (scan2400_kernel<kConvMagU16>, grid, block, 0, stream, p); break;
+    case kConvUc8Lut: case kConvUc8LutPower: SCAN (kConvUc8Lut); break;
+    case kConvUc8Generic:     SCAN (kConvUc8Generic); break;
+    case kConvSc16Int:        SCAN (kConvSc16Int); break;
+    case kConvSc16Generic:    SCAN (kConvSc16Generic); break;
+    case kConvSc16Q11Generic: SCAN (kConvSc16Q11Generic); break;
+    case kConvMagU16:         SCAN (kConvMagU16); break;
     default: return hipErrorInvalidValue;
   }
+#undef SCAN
   return hipGetLastError ();
 }
 
