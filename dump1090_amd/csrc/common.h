@@ -173,7 +173,7 @@ struct D8Params {
 };
 
 struct EmitParams {
-  const Record   *records; const uint32_t *counts; const uint32_t *acc_counts; const uint64_t *chunk_sum;   // exclusive scan of acc_counts per 1024-strip chunk
+  const Record   *records; const uint32_t *counts; const uint32_t *acc_counts; const uint64_t *offsets;     // messages of all earlier strips
   uint32_t        cap, nstrips;
   // stream geometry for timestamps and the signal level
   const uint8_t  *iq; uint64_t nsamples, navail; const uint16_t *halo; uint32_t ov, block_samples; int32_t conv;

@@ -145,8 +145,13 @@ struct modes_engine {
   DevBuf<Record> d8_records, d8_rec_packed;
   unsigned long long *d_stats = nullptr;
   uint32_t cap = 0;
-  // results
+  // results: the device accept path lands its messages in pinned host memory (one DMA, no staging copies);
+  // the host-ordered paths build `messages`
   std::vector<modes_message> messages;
+  modes_message *pin_msgs = nullptr;
+  size_t pin_cap = 0, pin_n = 0;
+  bool in_pinned = false;
+  unsigned long long *pin_small = nullptr;   // 32 words: totals and statistics read back once per run
   modes_stats stats;
 };
 
@@ -179,7 +184,8 @@ int setup_tables (modes_engine *e)
     if (bits == kShortBits) { t.short_tab = p; t.short_n = int (d.size ()); t.bloom_short = pb; }
     else                    { t.long_tab = p;  t.long_n = int (d.size ()); t.bloom_long = pb; }
   }
-  HIP_TRY (hipMalloc (reinterpret_cast<void **> (&e->d_stats), 8 * sizeof (unsigned long long)));
+  HIP_TRY (hipMalloc (reinterpret_cast<void **> (&e->d_stats), 32 * sizeof (unsigned long long)));
+  HIP_TRY (hipHostMalloc (reinterpret_cast<void **> (&e->pin_small), 32 * sizeof (unsigned long long), hipHostMallocDefault));
   if (e->cfg.sample_rate == 2000000) {
     std::vector<uint16_t> l10 (65536);
     build_log10_lut (l10.data ());
@@ -272,18 +278,20 @@ int run_accept_on_device (modes_engine *e, const ScanParams &sp, uint64_t first_
   }
   e->stats.replay_rounds = rounds;
 
-  // totals of accepted messages, then emit in order
+  // totals of accepted messages and the block statistics, read back together with the scan's totals: one sync
   uint64_t *d_totals = reinterpret_cast<uint64_t *> (e->d_stats);
-  HIP_TRY (launch_count_scan (e->acc_counts.p, e->vp_counts.p, sp.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p, d_totals, stream));
-  unsigned long long tot[3];
-  std::vector<uint32_t> bst (size_t (nblocks) * kBlkStats);
-  HIP_TRY (hipMemcpyAsync (tot, d_totals, sizeof tot, hipMemcpyDeviceToHost, stream));
-  HIP_TRY (hipMemcpyAsync (bst.data (), e->blk_stats.p, bst.size () * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
+  HIP_TRY (launch_count_scan (e->acc_counts.p, e->vp_counts.p, sp.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p, d_totals + 4, stream));
+  HIP_TRY (launch_blk_stats_sum (e->blk_stats.p, nblocks, e->d_stats + 8, stream));
+  HIP_TRY (hipMemcpyAsync (e->pin_small, d_totals, 32 * sizeof (unsigned long long), hipMemcpyDeviceToHost, stream));
   HIP_TRY (hipMemcpyAsync (e->cache.raw (), d_cache_out, kIcaoSlots * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
   HIP_TRY (hipStreamSynchronize (stream));
+  (void) hipEventElapsedTime (&e->kernel_ms[0], e->ev[0], e->ev[1]);
+  e->kernel_ms[1] = 0;
+  const unsigned long long *st = e->pin_small, *tot = e->pin_small + 4, *sum = e->pin_small + 8;
+  if (st[2]) return fail (MODES_E_OVERFLOW, "%llu strips overflowed their candidate slots (cap %u)", st[2], e->cap);
+  e->stats.valid_preamble = st[1];
+  e->stats.candidates = st[0];
   const size_t nm = size_t (tot[0]);
-  uint64_t sum[kBlkStats] = { 0 };
-  for (uint32_t b = 0; b < nblocks; b++) for (int k = 0; k < kBlkStats; k++) sum[k] += bst[size_t (b) * kBlkStats + k];
   e->stats.demodulated = sum[kStDemodulated]; e->stats.out_of_phase = sum[kStOutOfPhase];
   e->stats.CRC_good = sum[kStGood]; e->stats.CRC_bad = sum[kStBad];
   e->stats.CRC_single_bit_fix = sum[kStFix1]; e->stats.CRC_two_bits_fix = sum[kStFix2];
@@ -294,20 +302,29 @@ int run_accept_on_device (modes_engine *e, const ScanParams &sp, uint64_t first_
   else e->stats.valid_preamble -= sum[kStSkippedVp];
   if (sum[kStAccepted] != nm) return fail (MODES_E_HIP, "accepted-count mismatch (%llu vs %zu)", (unsigned long long) sum[kStAccepted], nm);
 
-  e->messages.resize (nm);
+  e->in_pinned = true;
+  e->pin_n = nm;
   if (nm) {
     if ((rc = e->d_messages.reserve (nm)) != MODES_OK) return rc;
+    if (nm > e->pin_cap) {
+      if (e->pin_msgs) (void) hipHostFree (e->pin_msgs);
+      e->pin_msgs = nullptr; e->pin_cap = 0;
+      const size_t want = nm + nm / 4 + 1024;
+      HIP_TRY (hipHostMalloc (reinterpret_cast<void **> (&e->pin_msgs), want * sizeof (modes_message), hipHostMallocDefault));
+      e->pin_cap = want;
+    }
     EmitParams ep;
     memset (&ep, 0, sizeof ep);
-    ep.records = e->records.p; ep.counts = e->counts.p; ep.acc_counts = e->acc_counts.p; ep.chunk_sum = e->chunk_sum.p;
+    ep.records = e->records.p; ep.counts = e->counts.p; ep.acc_counts = e->acc_counts.p; ep.offsets = e->offsets.p;
     ep.cap = e->cap; ep.nstrips = sp.nstrips;
     ep.iq = sp.iq; ep.nsamples = sp.nsamples; ep.navail = sp.navail; ep.halo = sp.halo; ep.ov = sp.ov;
     ep.block_samples = sp.block_samples; ep.conv = sp.conv; ep.lut256 = sp.lut256;
     ep.first_sample = first_sample; ep.sample_rate = e->cfg.sample_rate;
     ep.messages = e->d_messages.p;
     ep.mode = e->mode;
+    HIP_TRY (launch_strip_offsets (e->acc_counts.p, sp.nstrips, e->chunk_sum.p, e->offsets.p, stream));
     HIP_TRY (launch_emit2400 (ep, stream));
-    HIP_TRY (hipMemcpyAsync (e->messages.data (), e->d_messages.p, nm * sizeof (modes_message), hipMemcpyDeviceToHost, stream));
+    HIP_TRY (hipMemcpyAsync (e->pin_msgs, e->d_messages.p, nm * sizeof (modes_message), hipMemcpyDeviceToHost, stream));
     HIP_TRY (hipStreamSynchronize (stream));
   }
   return MODES_OK;
@@ -373,6 +390,8 @@ void modes_engine_destroy (modes_engine *e)
   if (e->tabs.log10_lut) (void) hipFree (e->tabs.log10_lut);
   if (e->tabs.crc_table) (void) hipFree (e->tabs.crc_table);
   if (e->d_stats) (void) hipFree (e->d_stats);
+  if (e->pin_small) (void) hipHostFree (e->pin_small);
+  if (e->pin_msgs) (void) hipHostFree (e->pin_msgs);
   for (hipEvent_t ev : e->ev) if (ev) (void) hipEventDestroy (ev);
   delete e;
 }
@@ -399,6 +418,7 @@ static int run_device_inner (modes_engine *e, const void *d_iq, size_t nbytes, u
   if (first_sample % e->block_samples) return fail (MODES_E_ARG, "first_sample must be a multiple of the block length");
   HIP_TRY (hipSetDevice (e->cfg.device));
   e->messages.clear ();
+  e->in_pinned = false; e->pin_n = 0;
   memset (&e->stats, 0, sizeof e->stats);
 
   ScanParams sp;
@@ -420,6 +440,9 @@ static int run_device_inner (modes_engine *e, const void *d_iq, size_t nbytes, u
   uint64_t *d_totals = reinterpret_cast<uint64_t *> (e->d_stats);
   HIP_TRY (launch_count_scan (e->counts.p, e->vp_counts.p, sp.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p,
                               d_totals, stream));
+  if (!e->cfg.host_replay && !e->cfg.phase_enhance)
+    return run_accept_on_device (e, sp, first_sample, stream);
+
   unsigned long long st[3];
   HIP_TRY (hipMemcpyAsync (st, d_totals, sizeof st, hipMemcpyDeviceToHost, stream));
   HIP_TRY (hipStreamSynchronize (stream));
@@ -429,9 +452,6 @@ static int run_device_inner (modes_engine *e, const void *d_iq, size_t nbytes, u
   const size_t nrec = size_t (st[0]);
   e->stats.valid_preamble = st[1];
   e->stats.candidates = nrec;
-
-  if (!e->cfg.host_replay && !e->cfg.phase_enhance)
-    return run_accept_on_device (e, sp, first_sample, stream);
 
   if ((rc = e->packed.reserve (nrec + 1)) != MODES_OK) return rc;
   if ((rc = e->packed_pos.reserve (nrec + 1)) != MODES_OK) return rc;
@@ -546,6 +566,7 @@ static int run_mode_ac_2400 (modes_engine *e, const void *d_iq, size_t nbytes, u
   HIP_TRY (hipMemcpyAsync (pos.data (), e->packed_pos.p, nrec * sizeof (uint64_t), hipMemcpyDeviceToHost, stream));
   HIP_TRY (hipStreamSynchronize (stream));
 
+  if (e->in_pinned) { e->messages.assign (e->pin_msgs, e->pin_msgs + e->pin_n); e->in_pinned = false; }
   std::vector<modes_message> ac;
   accept_pass_2400ac (recs.data (), pos.data (), nrec, B, first_sample, e->cfg.sample_rate, ac);
   e->stats.valid_preamble += ac.size ();                       // ref: src/demod-2400AC.c:215-216
@@ -569,6 +590,7 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   if (first_sample % e->block_samples) return fail (MODES_E_ARG, "first_sample must be a multiple of the block length");
   HIP_TRY (hipSetDevice (e->cfg.device));
   e->messages.clear ();
+  e->in_pinned = false; e->pin_n = 0;
   memset (&e->stats, 0, sizeof e->stats);
   const uint32_t B = e->block_samples;
   const uint64_t nsamples = nbytes / bytes_per_sample (e->cfg.input_format);
@@ -749,8 +771,13 @@ int modes_engine_time_scan (modes_engine *e, const void *d_iq, size_t nbytes, in
   return MODES_OK;
 }
 
-size_t modes_engine_num_messages (const modes_engine *e) { return e ? e->messages.size () : 0; }
-const modes_message *modes_engine_messages (const modes_engine *e) { return e && !e->messages.empty () ? e->messages.data () : nullptr; }
+size_t modes_engine_num_messages (const modes_engine *e) { return !e ? 0 : e->in_pinned ? e->pin_n : e->messages.size (); }
+const modes_message *modes_engine_messages (const modes_engine *e)
+{
+  if (!e) return nullptr;
+  if (e->in_pinned) return e->pin_n ? e->pin_msgs : nullptr;
+  return e->messages.empty () ? nullptr : e->messages.data ();
+}
 
 int modes_engine_get_stats (const modes_engine *e, modes_stats *out)
 {

@@ -39,6 +39,8 @@ hipError_t launch_snapshots (const uint32_t *delta, uint32_t nblocks, const uint
                              uint32_t *chunk_entry, uint32_t *snap_in, uint32_t *cache_out, hipStream_t stream);
 hipError_t launch_snap_broadcast (const uint32_t *cache_in, uint32_t nblocks, uint32_t *snap_in, hipStream_t stream);
 hipError_t launch_emit2400 (const EmitParams &p, hipStream_t stream);
+hipError_t launch_strip_offsets (const uint32_t *acc_counts, uint32_t nstrips, const uint64_t *chunk_sum, uint64_t *offsets, hipStream_t stream);
+hipError_t launch_blk_stats_sum (const uint32_t *blk_stats, uint32_t nblocks, unsigned long long *out, hipStream_t stream);
 hipError_t launch_count_scan (const uint32_t *counts, const uint32_t *vp_counts, uint32_t nstrips, uint64_t *chunk_sum,
                               uint64_t *chunk_vp, uint64_t *chunk_ovf, uint64_t *totals, hipStream_t stream);
 hipError_t launch_gather (const uint32_t *counts, uint32_t nstrips, const uint64_t *chunk_sum, const Record *records,

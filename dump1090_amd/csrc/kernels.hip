@@ -624,6 +624,8 @@ struct AcceptLds {
   uint32_t cache[kIcaoSlots];
   uint32_t written[kIcaoSlots / 32];
   uint32_t counter[kBlkStats];
+  uint32_t prefix[64];        // records in the block's earlier strips
+  uint32_t accn[64];          // accepted messages per strip
 };
 
 __device__ __forceinline__ uint32_t rdlane (uint32_t v, int l) { return uint32_t (__builtin_amdgcn_readlane (int (v), l)); }
@@ -650,16 +652,32 @@ void accept_kernel (const AcceptParams p)
   uint32_t skip_until = 0;                                   // each demod_2400 call starts at j = 0
   uint32_t st_demod = 0, st_oop = 0, st_good = 0, st_bad = 0, st_fix1 = 0, st_fix2 = 0, st_unk = 0, st_vp = 0, st_modeac = 0;
 
-  for (uint32_t strip = first_strip; strip < last_strip; strip++) {
-    const uint32_t cnt = p.counts[strip];
-    uint32_t nacc = 0;
-    for (uint32_t base = 0; base < cnt; base += 64) {
-      const bool have = base + lane < cnt;
-      Record *rp = p.records + size_t (strip) * p.cap + base + lane;
+  // the block's records, 64 at a time across its strips: counts -> exclusive prefix in LDS, record g -> (strip, index)
+  const uint32_t nst = last_strip - first_strip;                        // <= 64
+  uint32_t total;
+  {
+    const uint32_t c = uint32_t (lane) < nst ? clean_count (p.counts[first_strip + lane]) : 0u;
+    const uint32_t incl = uint32_t (wave_incl_scan (int (c), lane));
+    w.prefix[lane] = incl - c;
+    w.accn[lane] = 0;
+    total = uint32_t (__shfl (int (incl), 63, 64));
+  }
+  __builtin_amdgcn_s_waitcnt (0xc07f);
+  __builtin_amdgcn_wave_barrier ();
+  {
+    for (uint32_t base = 0; base < total; base += 64) {
+      const uint32_t g = base + lane;
+      const bool have = g < total;
+      uint32_t sl = 0;                                                   // largest strip with prefix <= g
+#pragma unroll
+      for (uint32_t step = 32; step >= 1; step >>= 1)
+        if (sl + step < nst && w.prefix[sl + step] <= g) sl += step;
+      const uint32_t strip = first_strip + sl;
+      Record *rp = p.records + size_t (strip) * p.cap + (have ? g - w.prefix[sl] : 0u);
       Record r;
       if (have) { const uint4 *s4 = reinterpret_cast<const uint4 *> (rp); *reinterpret_cast<uint4 *> (&r) = s4[0]; *(reinterpret_cast<uint4 *> (&r) + 1) = s4[1]; }
       else memset (&r, 0, sizeof r);
-      const uint32_t j = (strip - first_strip) * kStrip + r.off;
+      const uint32_t j = sl * kStrip + r.off;
       // --- per-record facts ---
       uint32_t aa = (uint32_t (r.msg[1]) << 16) | (uint32_t (r.msg[2]) << 8) | r.msg[3];
       bool aa_changed = false;
@@ -755,7 +773,7 @@ void accept_kernel (const AcceptParams p)
       st_good  += __popcll (__ballot (is_acc && ebits == 0 && !modea));
       st_fix1  += __popcll (__ballot (is_acc && ebits == 1));
       st_fix2  += __popcll (__ballot (is_acc && ebits == 2));
-      nacc += __popcll (accepted);
+      if (is_acc) atomicAdd (&w.accn[sl], 1u);
       // write back: flags bit0 = accepted, pad[0..1] = score
       if (have) {
         const uint8_t nf = is_acc ? 1 : 0;
@@ -765,32 +783,36 @@ void accept_kernel (const AcceptParams p)
           *reinterpret_cast<int16_t *> (rp->pad) = sc16;
         }
       }
-      // valid preambles hidden inside the skipped-over part of accepted messages
-      if (p.vp_bitmap) {
-        for (u64 am = accepted; am; am &= am - 1) {
-          const int a = __builtin_ctzll (am);
-          const uint32_t ja = rdlane (j, a);
-          const uint32_t lo = ja + 1, hi = min (rdlane (my_skip, a), blk_len);      // positions [lo, hi) never examined
-          if (lo >= hi) continue;
+      // valid preambles hidden inside the skipped-over part of accepted messages: positions (j, my_skip) never examined
+      if (p.vp_bitmap && is_acc) {
+        const uint32_t lo = j + 1, hi = min (my_skip, blk_len);
+        if (lo < hi) {
           const uint64_t g0 = blk_pos0 + lo, g1 = blk_pos0 + hi;
-          const uint64_t wi = (g0 >> 6) + lane;
           uint32_t c = 0;
-          if (wi <= ((g1 - 1) >> 6)) {
+          for (uint64_t wi = g0 >> 6; wi <= ((g1 - 1) >> 6); wi++) {
             u64 bits = p.vp_bitmap[wi];
             if (wi == (g0 >> 6)) bits &= ~0ull << (g0 & 63);
             if (wi == ((g1 - 1) >> 6) && (g1 & 63)) bits &= (1ull << (g1 & 63)) - 1;
-            c = __popcll (bits);
+            c += __popcll (bits);
           }
           if (c) atomicAdd (&w.counter[kStSkippedVp], c);
         }
       }
     }
-    if (lane == 0 && p.acc_counts[strip] != nacc) p.acc_counts[strip] = nacc;
-    if (lane == 0) w.counter[kStAccepted] += nacc;
   }
   __builtin_amdgcn_s_waitcnt (0xc07f);
   __builtin_amdgcn_wave_barrier ();
-
+  if (uint32_t (lane) < nst) {
+    const uint32_t nacc = w.accn[lane];
+    if (p.acc_counts[first_strip + lane] != nacc) p.acc_counts[first_strip + lane] = nacc;
+  }
+  {
+    uint32_t nacc = uint32_t (lane) < nst ? w.accn[lane] : 0u;
+    for (int d = 32; d >= 1; d >>= 1) nacc += uint32_t (__shfl_xor (int (nacc), d, 64));
+    if (lane == 0) w.counter[kStAccepted] = nacc;
+  }
+  __builtin_amdgcn_s_waitcnt (0xc07f);
+  __builtin_amdgcn_wave_barrier ();
   // delta of this block + change detection against the previous round
   bool diff = false;
   for (int i = lane; i < int (kIcaoSlots); i += 64) {
@@ -831,7 +853,18 @@ void snap_chunk_scan_kernel (const uint32_t *chunk_last, uint32_t nchunks, const
   const uint32_t s = blockIdx.x * 256 + threadIdx.x;
   if (s >= kIcaoSlots) return;
   uint32_t cur = cache_in[s];
-  for (uint32_t c = 0; c < nchunks; c++) {
+  uint32_t c = 0;
+  for (; c + 8 <= nchunks; c += 8) {
+    uint32_t d[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) d[k] = chunk_last[size_t (c + k) * kIcaoSlots + s];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      chunk_entry[size_t (c + k) * kIcaoSlots + s] = cur;
+      if (d[k] & kDeltaWritten) cur = d[k] & ~kDeltaWritten;
+    }
+  }
+  for (; c < nchunks; c++) {
     chunk_entry[size_t (c) * kIcaoSlots + s] = cur;
     const uint32_t d = chunk_last[size_t (c) * kIcaoSlots + s];
     if (d & kDeltaWritten) cur = d & ~kDeltaWritten;
@@ -861,12 +894,84 @@ void snap_broadcast_kernel (const uint32_t *cache_in, uint32_t nblocks, uint32_t
   if (i < size_t (nblocks) * kIcaoSlots) snap_in[i] = cache_in[i % kIcaoSlots];
 }
 
+// sums of the per-block statistics: out[k] = sum over blocks of blk_stats[block][k]
+__global__ __launch_bounds__ (256)
+void blk_stats_sum_kernel (const uint32_t *blk_stats, uint32_t nblocks, unsigned long long *out)
+{
+  unsigned long long acc[kBlkStats];
+#pragma unroll
+  for (int k = 0; k < kBlkStats; k++) acc[k] = 0;
+  for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < nblocks; b += gridDim.x * 256) {
+    const uint4 *q = reinterpret_cast<const uint4 *> (blk_stats + size_t (b) * kBlkStats);
+    const uint4 a = q[0], c = q[1], d = q[2];
+    acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w; acc[4] += c.x; acc[5] += c.y; acc[6] += c.z; acc[7] += c.w;
+    acc[8] += d.x; acc[9] += d.y; acc[10] += d.z; acc[11] += d.w;
+  }
+#pragma unroll
+  for (int k = 0; k < kBlkStats; k++) {
+    unsigned long long v = acc[k];
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor (v, d, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd (&out[k], v);
+  }
+}
+
+hipError_t launch_blk_stats_sum (const uint32_t *blk_stats, uint32_t nblocks, unsigned long long *out, hipStream_t stream)
+{
+  static_assert (kBlkStats == 12, "three uint4 per block");
+  hipError_t e = hipMemsetAsync (out, 0, kBlkStats * sizeof (unsigned long long), stream);
+  if (e != hipSuccess || nblocks == 0) return e;
+  const uint32_t grid = (nblocks + 255) / 256 < 64 ? (nblocks + 255) / 256 : 64;
+  hipLaunchKernelGGL (blk_stats_sum_kernel, dim3 (grid), dim3 (256), 0, stream, blk_stats, nblocks, out);
+  return hipGetLastError ();
+}
+
 // ---- emit: accepted records -> modes_message, in order, with the signal level ----
 struct MsgOut {            // mirrors modes_message (include/modes_hip.h), 56 bytes
   uint64_t timestamp; uint8_t msg[14]; uint8_t msg_bits, msg_type; uint32_t addr, crc; int16_t score; uint8_t error_bits, phase;
   uint32_t block; double sig_level; uint32_t j, reserved;
 };
 static_assert (sizeof (MsgOut) == 56, "modes_message layout");
+
+// MODES_NON_ICAO_ADDRESS from the message held as two little-endian words (bytes 0..7, 8..13)
+__device__ __forceinline__ uint32_t non_icao_flag_words (u64 lo, u64 hi, int df)
+{
+  uint8_t msg[14];
+#pragma unroll
+  for (int b = 0; b < 8; b++) msg[b] = uint8_t (lo >> (8 * b));
+#pragma unroll
+  for (int b = 0; b < 6; b++) msg[8 + b] = uint8_t (hi >> (8 * b));
+  return non_icao_flag_dev (msg, df);
+}
+
+// offsets[strip] = messages of all earlier strips: chunk base + exclusive scan inside the 1024-strip chunk
+__global__ __launch_bounds__ (256)
+void strip_offsets_kernel (const uint32_t *acc_counts, uint32_t nstrips, const uint64_t *chunk_sum, uint64_t *offsets)
+{
+  __shared__ uint32_t wsum[4];
+  const uint32_t base = blockIdx.x * kScanChunk + threadIdx.x * 4;
+  uint32_t c[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) c[k] = base + k < nstrips ? acc_counts[base + k] : 0u;
+  const uint32_t mine = c[0] + c[1] + c[2] + c[3];
+  const uint32_t incl = uint32_t (wave_incl_scan (int (mine), threadIdx.x & 63));
+  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+  __syncthreads ();
+  uint32_t before = incl - mine;
+  for (uint32_t wv = 0; wv < (threadIdx.x >> 6); wv++) before += wsum[wv];
+  uint64_t o = chunk_sum[blockIdx.x] + before;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { if (base + k < nstrips) offsets[base + k] = o; o += c[k]; }
+}
+
+hipError_t launch_strip_offsets (const uint32_t *acc_counts, uint32_t nstrips, const uint64_t *chunk_sum, uint64_t *offsets, hipStream_t stream)
+{
+  if (nstrips == 0) return hipSuccess;
+  static_assert (kScanChunk == 1024, "256 threads x 4 strips");
+  hipLaunchKernelGGL (strip_offsets_kernel, dim3 ((nstrips + kScanChunk - 1) / kScanChunk), dim3 (256), 0, stream, acc_counts, nstrips, chunk_sum, offsets);
+  return hipGetLastError ();
+}
+
+__device__ __forceinline__ uint32_t bcast (uint32_t v, int l) { return uint32_t (__builtin_amdgcn_readlane (int (v), l)); }
 
 template <int CONV>
 __global__ __launch_bounds__ (256)
@@ -877,70 +982,108 @@ void emit2400_kernel (const EmitParams p)
   if (strip >= p.nstrips) return;
   const uint32_t nacc = p.acc_counts[strip];
   if (!nacc) return;
-  // offset of this strip in the output = chunk base + accepted counts of the earlier strips of the chunk
-  const uint32_t chunk = strip / kScanChunk, first = chunk * kScanChunk;
-  uint64_t before = 0;
-  for (uint32_t i = first + lane; i < strip; i += 64) before += p.acc_counts[i];
-  for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor (before, d, 64);
-  MsgOut *out = reinterpret_cast<MsgOut *> (p.messages) + p.chunk_sum[chunk] + before;
+  MsgOut *out = reinterpret_cast<MsgOut *> (p.messages) + p.offsets[strip];
   const Record *recs = p.records + size_t (strip) * p.cap;
-  uint32_t k = 0;
   const uint32_t nrec = p.counts[strip];
-  for (uint32_t i = 0; k < nacc && i < nrec; i++) {
-    const Record r = recs[i];                     // same record for every lane
-    if (!(r.flags & 1)) continue;
-    const uint64_t P = uint64_t (strip) * kStrip + r.off;
-    const int mbits = msg_bits_for_df (r.df);
-    const int slen = mbits * 12 / 5;
-    u64 acc = 0;                                  // ref: src/demod-2400.c:486-497
-    for (int q = lane; p.mode != 2000 && q < slen; q += 64) {
-      const uint32_t m = CONV == kConvMagU16 ? 0u : mag_of_V<CONV> (p.iq, p.nsamples, p.halo, p.ov, p.block_samples, p.lut256, (long long) P + 19 + q);
-      acc += u64 (m * m);
-    }
-    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor (acc, d, 64);
-    if (lane == 0) {
-      MsgOut o;
-      memset (&o, 0, sizeof o);
-      const uint64_t blk = P / p.block_samples, j = P % p.block_samples;
-      const uint64_t counter = p.first_sample + blk * p.block_samples;
-      const uint64_t block_ts = uint64_t ((double (counter) * 12E6) / double (p.sample_rate));        // ref: src/infile.c:143
-      o.timestamp = p.mode == 2000 ? block_ts + j * 6                                                  // ref: src/demod-2000.c:960
-                                   : block_ts + j * 5 + r.phase;                                       // ref: src/demod-2400.c:467
-      for (int b = 0; b < 14; b++) o.msg[b] = r.msg[b];
-      const bool ap = r.cls == kClsAP || r.cls == kClsAP2, acq = r.cls == kClsDF11;
-      if (r.cls == kClsModeA) {                   // ref: src/demod-2000.c:318,677-701, src/dump1090.c:2722-2766
-        const uint32_t code = (uint32_t (r.msg[0]) << 8) | r.msg[1];
-        o.timestamp = block_ts + (j + 1) * 6;
-        o.msg_bits = 16; o.msg_type = 32;
-        o.addr = (code & 0x0000FF7Fu) | kNonIcao;
-        o.score = -1;
-        o.block = uint32_t (p.first_sample / p.block_samples + blk);
-        const int lv = int (r.crc);
-        o.sig_level = double (int (uint32_t (lv) * uint32_t (lv))) / (65535.0 * 65535.0);   // int product as the reference forms it
-        o.j = uint32_t (j);
-        out[k] = o;
-      } else {
-      int eb = 0;
-      if (acq && (r.crc & 0xFFFF80u)) eb = r.nerr;
-      if (!ap && !acq && r.crc) eb = r.nerr;
-      if (eb >= 1) o.msg[r.bit0 >> 3] ^= uint8_t (0x80u >> (r.bit0 & 7));
-      if (eb >= 2) o.msg[r.bit1 >> 3] ^= uint8_t (0x80u >> (r.bit1 & 7));
-      const uint32_t aa = (uint32_t (o.msg[1]) << 16) | (uint32_t (o.msg[2]) << 8) | o.msg[3];
-      o.msg_bits = uint8_t (mbits);
-      o.msg_type = uint8_t (r.df >= 24 ? 24 : r.df);
-      o.addr = ap ? r.crc : acq ? aa : (aa | non_icao_flag_dev (o.msg, r.df));
-      o.crc = r.crc;
-      o.score = *reinterpret_cast<const int16_t *> (r.pad);
-      o.error_bits = uint8_t (eb);
-      o.phase = p.mode == 2000 ? uint8_t (0) : r.phase;
-      o.block = uint32_t (p.first_sample / p.block_samples + blk);
-      // demod_2000's sig_level is wiped by decode_mode_S_message's memset (ref: src/demod-2000.c:966, src/dump1090.c:2385)
-      o.sig_level = p.mode == 2000 ? 0.0 : (double (acc) / 65535.0 / 65535.0) / double (slen);
-      o.j = uint32_t (j);
-      out[k] = o;
+  constexpr int bps = (CONV == kConvUc8Generic || CONV == kConvMagU16) ? 2 : 4;      // bytes per sample where the fast path applies
+  uint32_t k = 0;
+  for (uint32_t rb = 0; rb < nrec && k < nacc; rb += 64) {
+    uint4 ra = { 0, 0, 0, 0 }, rc = { 0, 0, 0, 0 };
+    if (rb + lane < nrec) { const uint4 *s4 = reinterpret_cast<const uint4 *> (recs + rb + lane); ra = s4[0]; rc = s4[1]; }
+    for (u64 accm = __ballot ((rc.z >> 16) & 1u); accm; accm &= accm - 1, k++) {        // flags bit 0
+      const int src = __builtin_ctzll (accm);
+      const uint32_t d0 = bcast (ra.x, src), d1 = bcast (ra.y, src), crc = bcast (ra.z, src), d3 = bcast (ra.w, src);
+      const uint32_t d4 = bcast (rc.x, src), d5 = bcast (rc.y, src), d6 = bcast (rc.z, src), d7 = bcast (rc.w, src);
+      const uint32_t off = d0 & 0xFFFF, phase = (d0 >> 16) & 0xFF, df = d0 >> 24;
+      const uint32_t cls = d1 & 0xFF, nerr = (d1 >> 8) & 0xFF, bit0 = (d1 >> 16) & 0xFF, bit1 = d1 >> 24;
+      u64 mlo = (u64 (d4) << 32) | d3, mhi = (u64 (d6 & 0xFFFF) << 32) | d5;           // msg[0..7], msg[8..13]
+      const int16_t score = int16_t ((d6 >> 24) | ((d7 & 0xFF) << 8));                   // pad[0..1]
+      const uint64_t P = uint64_t (strip) * kStrip + off;
+      const int mbits = msg_bits_for_df (int (df));
+      const int slen = mbits * 12 / 5;
+      u64 acc = 0;                                  // ref: src/demod-2400.c:486-497
+      if (p.mode != 2000 && CONV != kConvMagU16) {
+        const long long n0 = (long long) P + 19 - (long long) p.ov;                     // first sample of the sum
+        const bool lut = CONV == kConvUc8Lut || CONV == kConvUc8LutPower;
+        if (!lut && n0 >= 0 && uint64_t (n0) + 320 <= p.nsamples) {
+          // inside the shard: the (at most) five loads of a lane are issued together
+          uint32_t raw[5];
+#pragma unroll
+          for (int q = 0; q < 5; q++) {
+            const int x = lane + 64 * q;
+            if (bps == 2) raw[q] = reinterpret_cast<const uint16_t *> (p.iq)[n0 + x];
+            else          raw[q] = reinterpret_cast<const uint32_t *> (p.iq)[n0 + x];
+          }
+#pragma unroll
+          for (int q = 0; q < 5; q++) {
+            const int x = lane + 64 * q;
+            uint32_t m;
+            if (CONV == kConvUc8Generic) m = mag_from_float (c_uc8_float[raw[q] & 0xFF], c_uc8_float[(raw[q] >> 8) & 0xFF], nullptr);
+            else if (CONV == kConvSc16Int) m = mag_sc16_word (raw[q]) & 0xFFFFu;
+            else {
+              const float sc = CONV == kConvSc16Generic ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
+              m = mag_from_float (float (int16_t (raw[q] & 0xFFFF)) * sc, float (int16_t (raw[q] >> 16)) * sc, nullptr);
+            }
+            if (x < slen) acc += u64 (m * m);
+          }
+        } else {
+          for (int q = lane; q < slen; q += 64) {
+            const uint32_t m = mag_of_V<CONV> (p.iq, p.nsamples, p.halo, p.ov, p.block_samples, p.lut256, (long long) P + 19 + q);
+            acc += u64 (m * m);
+          }
+        }
+      }
+      for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor (acc, d, 64);
+      if (lane == 0) {
+        const uint64_t blk = P / p.block_samples, j = P % p.block_samples;
+        const uint64_t counter = p.first_sample + blk * p.block_samples;
+        const uint64_t block_ts = uint64_t ((double (counter) * 12E6) / double (p.sample_rate));        // ref: src/infile.c:143
+        uint64_t ts = p.mode == 2000 ? block_ts + j * 6                                                  // ref: src/demod-2000.c:960
+                                     : block_ts + j * 5 + phase;                                         // ref: src/demod-2400.c:467
+        const bool ap = cls == kClsAP || cls == kClsAP2, acq = cls == kClsDF11;
+        uint32_t msg_bits, msg_type, addr, ocrc = 0, eb = 0, oph = 0;
+        int16_t oscore;
+        double sig;
+        if (cls == kClsModeA) {                     // ref: src/demod-2000.c:318,677-701, src/dump1090.c:2722-2766
+          const uint32_t code = ((d3 & 0xFF) << 8) | ((d3 >> 8) & 0xFF);
+          ts = block_ts + (j + 1) * 6;
+          msg_bits = 16; msg_type = 32;
+          addr = (code & 0x0000FF7Fu) | kNonIcao;
+          oscore = -1;
+          const int lv = int (crc);
+          sig = double (int (uint32_t (lv) * uint32_t (lv))) / (65535.0 * 65535.0);   // int product as the reference forms it
+        } else {
+          if (acq && (crc & 0xFFFF80u)) eb = nerr;
+          if (!ap && !acq && crc) eb = nerr;
+          if (eb >= 1) { const uint32_t b = bit0 >> 3; const u64 f = u64 (0x80u >> (bit0 & 7)); if (b < 8) mlo ^= f << (8 * b); else mhi ^= f << (8 * (b - 8)); }
+          if (eb >= 2) { const uint32_t b = bit1 >> 3; const u64 f = u64 (0x80u >> (bit1 & 7)); if (b < 8) mlo ^= f << (8 * b); else mhi ^= f << (8 * (b - 8)); }
+          const uint32_t aa = (uint32_t (mlo >> 8) & 0xFF) << 16 | (uint32_t (mlo >> 16) & 0xFF) << 8 | (uint32_t (mlo >> 24) & 0xFF);
+          msg_bits = uint32_t (mbits);
+          msg_type = df >= 24 ? 24 : df;
+          addr = ap ? crc : acq ? aa : (aa | non_icao_flag_words (mlo, mhi, int (df)));
+          ocrc = crc;
+          oscore = score;
+          oph = p.mode == 2000 ? 0u : phase;
+          // demod_2000's sig_level is wiped by decode_mode_S_message's memset (ref: src/demod-2000.c:966, src/dump1090.c:2385)
+          sig = p.mode == 2000 ? 0.0 : (double (acc) / 65535.0 / 65535.0) / double (slen);
+        }
+        const u64 sigbits = u64 (__double_as_longlong (sig));
+        uint4 o0, o1, o2; uint2 o3;
+        o0.x = uint32_t (ts); o0.y = uint32_t (ts >> 32); o0.z = uint32_t (mlo); o0.w = uint32_t (mlo >> 32);
+        o1.x = uint32_t (mhi); o1.y = (uint32_t (mhi >> 32) & 0xFFFFu) | (msg_bits << 16) | (msg_type << 24); o1.z = addr; o1.w = ocrc;
+        o2.x = uint32_t (uint16_t (oscore)) | (eb << 16) | (oph << 24); o2.y = uint32_t (p.first_sample / p.block_samples + blk);
+        o2.z = uint32_t (sigbits); o2.w = uint32_t (sigbits >> 32);
+        o3.x = uint32_t (j); o3.y = 0;
+        uint32_t *dst = reinterpret_cast<uint32_t *> (out + k);
+        *reinterpret_cast<uint2 *> (dst) = make_uint2 (o0.x, o0.y);
+        *reinterpret_cast<uint2 *> (dst + 2) = make_uint2 (o0.z, o0.w);
+        *reinterpret_cast<uint2 *> (dst + 4) = make_uint2 (o1.x, o1.y);
+        *reinterpret_cast<uint2 *> (dst + 6) = make_uint2 (o1.z, o1.w);
+        *reinterpret_cast<uint2 *> (dst + 8) = make_uint2 (o2.x, o2.y);
+        *reinterpret_cast<uint2 *> (dst + 10) = make_uint2 (o2.z, o2.w);
+        *reinterpret_cast<uint2 *> (dst + 12) = o3;
       }
     }
-    k++;
   }
 }
 
