@@ -304,11 +304,12 @@ __device__ __forceinline__ uint16_t mag_of_sample (const uint16_t *lut, const Sc
   return mag_from_float (float (s[0]) * sc, float (s[1]) * sc, nullptr);
 }
 
-template <int CONV, int kCount>
+// kLanes = 64: a wave stages its own tile; kLanes = 256: the four waves of a workgroup stage a shared tile (lane = threadIdx.x)
+template <int CONV, int kCount, int kLanes = 64>
 __device__ __forceinline__ void stage_tile_pos (uint16_t *tile, const uint16_t *lut, const ScanParams &p, long long s0, int lane)
 {
   constexpr int kChunks = TileChunks<kCount>::n;
-  constexpr int kIters = (kChunks + 63) / 64;
+  constexpr int kIters = (kChunks + kLanes - 1) / kLanes;
   constexpr int NW = RawWords<CONV>::n;
   const long long N = (long long) (CONV == kConvMagU16 ? p.navail : p.nsamples);
   const long long a_lo = (s0 >= 0 ? s0 : s0 - 7) / 8 * 8;
@@ -317,12 +318,12 @@ __device__ __forceinline__ void stage_tile_pos (uint16_t *tile, const uint16_t *
     uint32_t raw[kIters][NW];
 #pragma unroll
     for (int it = 0; it < kIters; it++) {
-      const int ch = it * 64 + lane;
+      const int ch = it * kLanes + lane;
       if (ch < kChunks) load_raw8<CONV> (p, a_lo + 8 * ch, raw[it]);
     }
 #pragma unroll
     for (int it = 0; it < kIters; it++) {
-      const int ch = it * 64 + lane;
+      const int ch = it * kLanes + lane;
       if (ch < kChunks) {
         const uint4 pk = convert_raw8<CONV> (lut, raw[it]);
         uint16_t *dst = tile + 8 * ch - shift;
@@ -339,7 +340,7 @@ __device__ __forceinline__ void stage_tile_pos (uint16_t *tile, const uint16_t *
     return;
   }
   // first / last strips of the shard: per-sample bounds
-  for (int c = lane * 8; c < (kCount + 7) / 8 * 8; c += 64 * 8) {
+  for (int c = lane * 8; c < (kCount + 7) / 8 * 8; c += kLanes * 8) {
     uint16_t out[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) out[k] = mag_of_sample<CONV> (lut, p, s0 + c + k, N);

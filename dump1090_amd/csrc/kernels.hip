@@ -18,16 +18,16 @@ namespace modes {
 
 
 // LDS per wave
-constexpr int kTileN = 8 * TileChunks<kStrip + kLook2400>::n;
+constexpr int kWavesPerBlock = 4;
+constexpr int kGroupSpan = kWavesPerBlock * kStrip;             // positions one workgroup scans
+constexpr int kTileN = 8 * TileChunks<kGroupSpan + kLook2400>::n;
 constexpr int kQ1Seg = 256;
 template <bool PE> struct WaveLds {
-  alignas (16) uint16_t tile[kTileLead + kTileN];   // tile[kTileLead + x] = V[P0 + x]
   uint16_t q1[kQ1Seg];                              // off | pattern << 12, kQ1Seg candidates at a time
   uint32_t q2[PE ? 5 * 64 : 64];                    // off | (t-4) << 12 | df << 16, one stage-C batch at a time
   uint32_t vp[kStrip / 32];                         // valid-preamble bit per position of the strip
 };
 
-constexpr int kWavesPerBlock = 4;
 
 __device__ __forceinline__ uint32_t alignbit (uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit (hi, lo, sh); }
 
@@ -80,6 +80,7 @@ void scan2400_kernel (const ScanParams p)
 {
   constexpr bool kLut = CONV == kConvUc8Lut || CONV == kConvUc8LutPower;
   __shared__ WaveLds<PE> lds[kWavesPerBlock];
+  __shared__ __attribute__ ((aligned (16))) uint16_t s_tile[kTileLead + kTileN];   // s_tile[kTileLead + x] = V[G0 + x], shared by the four waves
   __shared__ uint16_t s_lut[kLut ? 256 : 1];        // as-written uc8 table
   const int lane = lane_id ();
   const int wv = threadIdx.x >> 6;
@@ -89,7 +90,6 @@ void scan2400_kernel (const ScanParams p)
     __syncthreads ();
   }
   const uint32_t strip = blockIdx.x * kWavesPerBlock + wv;
-  if (strip >= p.nstrips) return;
   w.vp[lane] = 0;
 
   // stage D maps lane -> message bit (lane ^ 7) (+ 64 in the second round): a ballot then holds the message bytes as they
@@ -97,13 +97,14 @@ void scan2400_kernel (const ScanParams p)
   const int bl = lane ^ 7;
   const uint32_t sbL0 = c_single_bit[bl], sbL1 = bl < 48 ? c_single_bit[64 + bl] : 0u, sbS = bl < 56 ? c_single_bit[56 + bl] : 0u;
 
-  // ---- stage A: magnitudes V[P0 .. P0 + kStrip + kLook2400) into LDS ----
+  // ---- stage A: magnitudes V[G0 .. G0 + 4 strips + kLook2400) into LDS, staged by the whole workgroup ----
+  const long long G0 = (long long) blockIdx.x * kGroupSpan;
+  const long long s0 = G0 - (long long) (CONV == kConvMagU16 ? 0u : p.ov);   // sample index of V[G0] (may be < 0)
+  stage_tile_pos<CONV, kGroupSpan + kLook2400, 64 * kWavesPerBlock> (s_tile + kTileLead, s_lut, p, s0, int (threadIdx.x));
+  __syncthreads ();
+  if (strip >= p.nstrips) return;
   const long long P0 = (long long) strip * kStrip;
-  const long long s0 = P0 - (long long) (CONV == kConvMagU16 ? 0u : p.ov);   // sample index of V[P0] (may be < 0)
-  uint16_t *V = w.tile + kTileLead;
-  stage_tile_pos<CONV, kStrip + kLook2400> (V, s_lut, p, s0, lane);
-  __builtin_amdgcn_s_waitcnt (0xc07f);   // lgkmcnt(0): LDS writes of this wave are done (wave-private data)
-  __builtin_amdgcn_wave_barrier ();
+  const uint16_t *V = s_tile + kTileLead + wv * kStrip;
 
   if (p.debug_stop == 1) { if (lane == 0) p.counts[strip] = V[lane]; return; }
 
@@ -183,12 +184,12 @@ void scan2400_kernel (const ScanParams p)
     __builtin_amdgcn_wave_barrier ();
     const int nseg = min (n1 - seg, kQ1Seg);
 
-    for (int base = 0; base < nseg && !overflow; base += 64) {
-      // ---- stage C: amplitude tests + phase pick, one lane per candidate ----
+    // ---- stage C1: amplitude tests, one lane per candidate; survivors (about one in four) are compacted in place ----
+    int nsurv = 0;
+    for (int base = 0; base < nseg; base += 64) {
       const int qi = base + lane;
-      bool pass = false;
-      int off = 0, nent = 0;
-      uint32_t ent[PE ? 5 : 1];
+      bool amp = false;
+      int off = 0;
       if (qi < nseg) {
         const uint32_t qe = w.q1[qi];
         off = qe & 0xFFF;
@@ -204,8 +205,26 @@ void scan2400_kernel (const ScanParams p)
         const uint32_t sig = uint32_t ((pat == 4 ? 0 : s[1]) + (pat <= 1 ? s39 : 0) + (pat >= 3 ? s410 : 0) + (pat == 0 ? 0 : s[12]));
         const uint32_t noise = uint32_t (s[6] + s[7] + ((pat == 2 || pat == 4) ? 0 : s[5]) + ((pat == 0 || pat == 2) ? 0 : s[8]));
         const int quiet = max (max (max (s[5], s[6]), max (s[7], s[8])), max (max (max (s[14], s[15]), max (s[16], s[17])), s[18]));
-        pass = !(sig * 2 < 3 * noise) && quiet < high;                                    // ref: :292, :297-308
-        if (pass) {
+        amp = !(sig * 2 < 3 * noise) && quiet < high;                                     // ref: :292, :297-308
+      }
+      const u64 am = __ballot (amp);
+      if (amp) w.q1[nsurv + __popcll (am & ((1ull << lane) - 1))] = uint16_t (off);       // nsurv + rank <= qi: in place
+      nsurv += __popcll (am);
+    }
+    __builtin_amdgcn_s_waitcnt (0xc07f);
+    __builtin_amdgcn_wave_barrier ();
+
+    for (int base = 0; base < nsurv && !overflow; base += 64) {
+      // ---- stage C2: phase pick (best_phase), one lane per surviving candidate ----
+      const int qi = base + lane;
+      bool pass = false;
+      int off = 0, nent = 0;
+      uint32_t ent[PE ? 5 : 1];
+      if (qi < nsurv) {
+        off = w.q1[qi];
+        const uint16_t *pp = V + off;
+        pass = true;
+        {
           int e[14], thr;
           {
             int d[15];
