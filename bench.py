@@ -108,8 +108,16 @@ def run_workload(name, args, world, rank, local, dev, want_cpu):
     # algorithmic bytes per sample: the IQ bytes the selected converter has to read
     alg_bps = 1 if (fmt == "uc8" and not power) else bps
     achieved = nsamples * alg_bps / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    traffic = args.traffic
+    if traffic is None and args.gib == 4.0 and nrec == 1:
+        # HBM bytes per launch of the scan kernel from the committed PMC passes (profiles/README.md), same size and seed
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as f:
+                traffic = json.load(f).get(name, {}).get("scan2400_traffic_bytes_per_launch")
+        except OSError:
+            traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": args.traffic, "kernel": kernel,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kernel,
                 "kernel_ms": round(kernel_ms, 4), "alg_bytes_per_sample": alg_bps}
     if k2:
         roofline["second_kernel"] = {"kernel": "d8_trig_kernel", "kernel_ms": round(k2 / args.steps / nrec, 4)}
