@@ -41,6 +41,14 @@ class Stats(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class DcInfo(C.Structure):
+    _fields_ = [("chunks", C.c_uint32), ("rerun_chunks", C.c_uint32), ("chunk_samples", C.c_uint64),
+                ("warm_samples", C.c_uint64), ("chain_ms", C.c_float), ("reserved", C.c_uint32)]
+
+    def asdict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+
+
 class ConvertState(C.Structure):
     _fields_ = [("DC_A", C.c_float), ("DC_B", C.c_float), ("z1_I", C.c_float), ("z1_Q", C.c_float),
                 ("func_name", C.c_char_p), ("description", C.c_char_p)]
@@ -122,6 +130,13 @@ def lib():
         L.modes_engine_halo_at.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p, C.c_void_p]
         L.modes_engine_tail_halo.restype = C.c_void_p
         L.modes_engine_tail_halo.argtypes = [C.c_void_p]
+        L.modes_engine_set_dc_state.argtypes = [C.c_void_p, C.c_float, C.c_float]
+        L.modes_engine_get_dc_state.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.modes_engine_set_dc_lead.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64]
+        L.modes_engine_get_dc_info.argtypes = [C.c_void_p, C.POINTER(DcInfo)]
+        L.modes_engine_dc_magnitudes.restype = C.c_void_p
+        L.modes_engine_dc_magnitudes.argtypes = [C.c_void_p]
+        L.modes_engine_read_dc_magnitudes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
         L.modes_convert_device.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(ConvertState),
                                            C.POINTER(C.c_double), C.c_void_p]
         L.modes_hip_bind.argtypes = [C.c_void_p]
@@ -228,6 +243,29 @@ class Engine:
         a = np.zeros(n, dtype=np.float64)
         if n:
             self.L.modes_engine_block_power(self.h, a.ctypes.data_as(C.c_void_p), n)
+        return a
+
+    # ---- float converters with the DC block on ----
+    def set_dc_state(self, z1_I=0.0, z1_Q=0.0):
+        _check(self.L.modes_engine_set_dc_state(self.h, z1_I, z1_Q))
+
+    def get_dc_state(self):
+        a, b = C.c_float(), C.c_float()
+        _check(self.L.modes_engine_get_dc_state(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def set_dc_lead(self, lead_samples, warm_samples=0):
+        _check(self.L.modes_engine_set_dc_lead(self.h, lead_samples, warm_samples))
+
+    def dc_info(self):
+        i = DcInfo()
+        _check(self.L.modes_engine_get_dc_info(self.h, C.byref(i)))
+        return i.asdict()
+
+    def dc_magnitudes(self, first, count):
+        """Magnitudes of the last filter_dc run: entry 0 = first overlap sample in front of the shard."""
+        a = np.zeros(count, dtype=np.uint16)
+        _check(self.L.modes_engine_read_dc_magnitudes(self.h, a.ctypes.data_as(C.c_void_p), first, count))
         return a
 
     def stats(self):

@@ -172,6 +172,24 @@ struct D8Params {
   uint32_t       *announce;      // [2^24 / 32] addresses that can enter the ICAO cache during the run, or null = no filter
 };
 
+// ---- float converters with the DC block on, whole recording (kernels_dc.hip) ----------------
+// One chain of the filter per chunk: it starts at sample `start` (<= the chunk's first sample, may reach back
+// into the lead-in in front of the shard) from the bracket [lo, hi] per channel; lo == hi when the state is known.
+struct DcChunk { long long start; float zIlo, zIhi, zQlo, zQhi; uint32_t chunk; uint32_t pad; };
+static_assert(sizeof(DcChunk) == 32, "DcChunk must be 32 bytes");
+
+struct DcParams {
+  const uint8_t  *iq;          // sample 0 of the shard (16-byte aligned); `start` may be negative
+  uint64_t        n;           // samples in the shard
+  uint64_t        chunk_len;   // samples per chunk, a multiple of 256
+  float           A, B;        // convert_state.DC_A, DC_B (ref: src/convert.c:349-353)
+  const DcChunk  *desc;        // one per launched wave
+  uint16_t       *mag;         // [n] magnitudes of the shard's samples (4-byte aligned)
+  float          *z_start;     // [nchunks][4] I-lo, I-hi, Q-lo, Q-hi in front of the chunk's first sample
+  float          *z_end;       // [nchunks][2] z1_I, z1_Q behind the chunk's last sample
+  uint32_t       *unmerged;    // [nchunks] 1 = the bracket was still open at the chunk's first sample
+};
+
 struct EmitParams {
   const Record   *records; const uint32_t *counts; const uint32_t *acc_counts; const uint64_t *offsets;     // messages of all earlier strips
   uint32_t        cap, nstrips;

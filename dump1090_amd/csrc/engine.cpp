@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cstdint>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -145,6 +146,14 @@ struct modes_engine {
   DevBuf<Record> d8_records, d8_rec_packed;
   unsigned long long *d_stats = nullptr;
   uint32_t cap = 0;
+  // float converters with the DC block on (kernels_dc.hip): V = [overlap | magnitudes] of the shard in HBM
+  DevBuf<uint16_t> dc_mag;
+  DevBuf<DcChunk> dc_desc;
+  DevBuf<float> dc_zs, dc_ze;
+  DevBuf<uint32_t> dc_unm;
+  float dc_A = 0.0f, dc_B = 1.0f, dc_z[2] = { 0.0f, 0.0f };
+  uint64_t dc_lead = 0, dc_warm = 0;
+  modes_dc_info dc_info;
   // results: the device accept path lands its messages in pinned host memory (one DMA, no staging copies);
   // the host-ordered paths build `messages`
   std::vector<modes_message> messages;
@@ -234,6 +243,106 @@ int fill_scan_params (modes_engine *e, const void *d_iq, size_t nbytes, const ui
   return MODES_OK;
 }
 
+
+// Float converter with the DC block on over the whole shard (ref: src/convert.c:112-245).  Fills e->dc_mag with the
+// virtual stream V = [overlap | magnitudes] and switches `sp` to read it.  See kernels_dc.hip for the decomposition:
+// independent chunks, each warmed up from a bracket that must have closed by the chunk's first sample; a chunk whose
+// bracket is still open -- or whose start state differs from the end state of the chunk before -- is re-run from that
+// exact end state, in order, so the result is the sequential one whatever the warm-up length.
+int prepare_dc (modes_engine *e, const void *d_iq, size_t nbytes, const uint16_t *d_halo, hipStream_t stream, ScanParams *sp)
+{
+  const int bps = bytes_per_sample (e->cfg.input_format);
+  const uint64_t n = nbytes / bps;
+  const uint32_t ov = e->ov, ovr = (ov + 7u) & ~7u;
+  if (reinterpret_cast<uintptr_t> (d_iq) & 15) return fail (MODES_E_ARG, "filter_dc: d_iq must be 16-byte aligned");
+  const uint64_t lead = e->dc_lead;
+  e->dc_lead = 0;                                                     // one run only
+  if (lead % 256) return fail (MODES_E_ARG, "filter_dc: the lead-in must be a multiple of 256 samples");
+  int rc;
+  if ((rc = e->dc_mag.reserve (size_t (n) + ov + 1024)) != MODES_OK) return rc;
+  uint16_t *V = e->dc_mag.p + 8;
+  const bool own_halo = lead >= ovr;                                  // the lead-in covers the overlap: the chain forms it
+  const uint64_t back = own_halo ? ovr : 0;                           // samples in front of the shard whose magnitude is kept
+  if (!own_halo) {
+    if (d_halo) HIP_TRY (hipMemcpyAsync (V, d_halo, ov * sizeof (uint16_t), hipMemcpyDeviceToDevice, stream));
+    else        HIP_TRY (hipMemsetAsync (V, 0, ov * sizeof (uint16_t), stream));
+  }
+  HIP_TRY (hipMemsetAsync (V + ov + n, 0, 512 * sizeof (uint16_t), stream));
+  memset (&e->dc_info, 0, sizeof e->dc_info);
+  sp->iq = reinterpret_cast<const uint8_t *> (V);
+  sp->conv = kConvMagU16;
+  sp->navail = n + ov;
+  sp->halo = nullptr;
+  if (n == 0) return MODES_OK;
+
+  const uint64_t n_eff = n + back, lead_eff = (lead - back) & ~255ull;   // chains start on the 256-sample grid of the shard
+  uint64_t K = n_eff / 65536;
+  if (K < 1) K = 1;
+  if (K > 1024) K = 1024;
+  const uint64_t L = ((n_eff + K - 1) / K + 255) / 256 * 256;
+  K = (n_eff + L - 1) / L;
+  uint64_t warm = e->dc_warm ? e->dc_warm : uint64_t (std::ceil (35.0 / double (e->dc_A)));
+  warm = (warm + 255) / 256 * 256;
+  const float bound = e->conv == kConvSc16Q11Generic ? 16.0f : 1.0f;  // |f| never exceeds it, so neither does |z1|
+  std::vector<DcChunk> desc (K);
+  for (uint64_t c = 0; c < K; c++) {
+    DcChunk &d = desc[c];
+    const uint64_t c0 = c * L;
+    d.chunk = uint32_t (c); d.pad = 0;
+    if (c0 + lead_eff <= warm) {
+      d.start = -(long long) lead_eff;
+      if (lead == 0) { d.zIlo = d.zIhi = e->dc_z[0]; d.zQlo = d.zQhi = e->dc_z[1]; }       // the stream's own state
+      else           { d.zIlo = d.zQlo = -bound; d.zIhi = d.zQhi = bound; }
+    } else {
+      d.start = (long long) (c0 - warm);
+      d.zIlo = d.zQlo = -bound; d.zIhi = d.zQhi = bound;
+    }
+  }
+  if ((rc = e->dc_desc.reserve (K + 1)) != MODES_OK) return rc;
+  if ((rc = e->dc_zs.reserve (4 * K)) != MODES_OK) return rc;
+  if ((rc = e->dc_ze.reserve (2 * K)) != MODES_OK) return rc;
+  if ((rc = e->dc_unm.reserve (K)) != MODES_OK) return rc;
+  DcParams q;
+  memset (&q, 0, sizeof q);
+  q.iq = static_cast<const uint8_t *> (d_iq) - back * bps;
+  q.n = n_eff; q.chunk_len = L; q.A = e->dc_A; q.B = e->dc_B;
+  q.desc = e->dc_desc.p; q.mag = V + ov - back;
+  q.z_start = e->dc_zs.p; q.z_end = e->dc_ze.p; q.unmerged = e->dc_unm.p;
+  hipEvent_t ea, eb;
+  HIP_TRY (hipEventCreate (&ea));
+  HIP_TRY (hipEventCreate (&eb));
+  HIP_TRY (hipMemcpyAsync (e->dc_desc.p, desc.data (), K * sizeof (DcChunk), hipMemcpyHostToDevice, stream));
+  HIP_TRY (hipEventRecord (ea, stream));
+  HIP_TRY (launch_dc_chain (e->conv, q, uint32_t (K), stream));
+  HIP_TRY (hipEventRecord (eb, stream));
+  std::vector<float> zs (4 * K), ze (2 * K);
+  std::vector<uint32_t> unm (K);
+  HIP_TRY (hipMemcpyAsync (zs.data (), e->dc_zs.p, 4 * K * sizeof (float), hipMemcpyDeviceToHost, stream));
+  HIP_TRY (hipMemcpyAsync (ze.data (), e->dc_ze.p, 2 * K * sizeof (float), hipMemcpyDeviceToHost, stream));
+  HIP_TRY (hipMemcpyAsync (unm.data (), e->dc_unm.p, K * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
+  HIP_TRY (hipStreamSynchronize (stream));
+  (void) hipEventElapsedTime (&e->dc_info.chain_ms, ea, eb);
+  (void) hipEventDestroy (ea);
+  (void) hipEventDestroy (eb);
+  e->dc_info.chunks = uint32_t (K); e->dc_info.chunk_samples = L; e->dc_info.warm_samples = warm;
+  if (unm[0]) return fail (MODES_E_ARG, "filter_dc: a lead-in of %llu samples does not settle the DC filter (about %llu needed)",
+                           (unsigned long long) lead, (unsigned long long) warm);
+  for (uint64_t c = 1; c < K; c++) {
+    const float *st = &zs[4 * c], *pe = &ze[2 * (c - 1)];
+    if (!unm[c] && st[0] == pe[0] && st[2] == pe[1]) continue;
+    DcChunk d;                                                        // re-run from the exact state
+    d.start = (long long) (c * L); d.chunk = uint32_t (c); d.pad = 0;
+    d.zIlo = d.zIhi = pe[0]; d.zQlo = d.zQhi = pe[1];
+    HIP_TRY (hipMemcpyAsync (e->dc_desc.p + K, &d, sizeof d, hipMemcpyHostToDevice, stream));
+    q.desc = e->dc_desc.p + K;
+    HIP_TRY (launch_dc_chain (e->conv, q, 1, stream));
+    HIP_TRY (hipMemcpyAsync (&ze[2 * c], e->dc_ze.p + 2 * c, 2 * sizeof (float), hipMemcpyDeviceToHost, stream));
+    HIP_TRY (hipStreamSynchronize (stream));
+    e->dc_info.rerun_chunks++;
+  }
+  e->dc_z[0] = ze[2 * (K - 1)]; e->dc_z[1] = ze[2 * (K - 1) + 1];
+  return MODES_OK;
+}
 
 // The ordered accept pass on the device: fixed-point rounds over the per-block ICAO snapshots, then emit.
 int run_accept_on_device (modes_engine *e, const ScanParams &sp, uint64_t first_sample, hipStream_t stream)
@@ -345,7 +454,8 @@ int modes_engine_create (const modes_engine_config *cfg, modes_engine **out)
   const int conv = select_converter (cfg->input_format, cfg->filter_dc != 0, cfg->compute_power != 0);
   if (conv < 0) return fail (MODES_E_ARG, "no suitable converter for format=%d power=%d DC=%d", cfg->input_format,
                              cfg->compute_power, cfg->filter_dc);
-  if (cfg->filter_dc) return fail (MODES_E_ARG, "DC-filter converters are not built yet");
+  if (cfg->filter_dc && cfg->mode_ac && cfg->sample_rate == 2400000)
+    return fail (MODES_E_ARG, "demod_2400_AC behind a DC-filter converter is not built (block mean_power)");
   int ndev = 0;
   if (hipGetDeviceCount (&ndev) != hipSuccess || ndev <= 0) return fail (MODES_E_NODEVICE, "no HIP device");
   if (cfg->device < 0 || cfg->device >= ndev) return fail (MODES_E_ARG, "device %d of %d", cfg->device, ndev);
@@ -359,6 +469,11 @@ int modes_engine_create (const modes_engine_config *cfg, modes_engine **out)
   e->mode = cfg->sample_rate == 2000000 ? 2000 : cfg->sample_rate == 8000000 ? 8000 : 2400;
   e->cap = e->mode == 2000 ? uint32_t (cfg->phase_enhance ? kCap2000PE : kCap2000) : cfg->phase_enhance ? 128 : 32;
   memset (&e->stats, 0, sizeof e->stats);
+  memset (&e->dc_info, 0, sizeof e->dc_info);
+  if (cfg->filter_dc) {                       // ref: src/convert.c:349-354
+    e->dc_B = float (exp (-2.0 * M_PI * 1.0 / double (cfg->sample_rate)));
+    e->dc_A = float (1.0 - e->dc_B);
+  }
   int rc = setup_tables (e);
   if (rc != MODES_OK) { modes_engine_destroy (e); return rc; }
   rc = e->tail.reserve (e->ov);
@@ -378,6 +493,7 @@ void modes_engine_destroy (modes_engine *e)
   e->blk_stats.release (); e->small_u32.release (); e->d_messages.release ();
   e->rssi_sum.release (); e->staging.release (); e->tail.release (); e->vp_bitmap.release ();
   e->block_power.release (); e->noise_level.release ();
+  e->dc_mag.release (); e->dc_desc.release (); e->dc_zs.release (); e->dc_ze.release (); e->dc_unm.release ();
   e->d8_trig.release (); e->d8_amb.release (); e->d8_off.release (); e->d8_p0.release (); e->d8_mx.release ();
   e->d8_win_count.release (); e->d8_chunk_rec.release (); e->d8_announce.release (); e->d8_table.release (); e->d8_entry.release ();
   e->d8_win_start.release (); e->d8_small.release (); e->d8_windows.release (); e->d8_win_packed.release ();
@@ -424,6 +540,7 @@ static int run_device_inner (modes_engine *e, const void *d_iq, size_t nbytes, u
   ScanParams sp;
   int rc = fill_scan_params (e, d_iq, nbytes, d_halo, &sp);
   if (rc != MODES_OK) return rc;
+  if (e->cfg.filter_dc && (rc = prepare_dc (e, d_iq, nbytes, d_halo, stream, &sp)) != MODES_OK) return rc;
   if (sp.nstrips == 0) return MODES_OK;
 
   HIP_TRY (hipEventRecord (e->ev[0], stream));
@@ -515,8 +632,8 @@ static int run_device_inner (modes_engine *e, const void *d_iq, size_t nbytes, u
     if ((rc = e->rssi_sum.reserve (nm)) != MODES_OK) return rc;
     HIP_TRY (hipMemcpyAsync (e->rssi_pos.p, mpos.data (), nm * sizeof (uint64_t), hipMemcpyHostToDevice, stream));
     HIP_TRY (hipMemcpyAsync (e->rssi_len.p, len.data (), nm * sizeof (uint32_t), hipMemcpyHostToDevice, stream));
-    HIP_TRY (launch_rssi2400 (e->conv, sp.iq, sp.nsamples, sp.halo, sp.ov, sp.block_samples, sp.lut256, e->rssi_pos.p,
-                              e->rssi_len.p, e->rssi_sum.p, uint32_t (nm), stream));
+    HIP_TRY (launch_rssi2400 (sp.conv, sp.iq, sp.conv == kConvMagU16 ? sp.navail : sp.nsamples, sp.halo, sp.ov, sp.block_samples,
+                              sp.lut256, e->rssi_pos.p, e->rssi_len.p, e->rssi_sum.p, uint32_t (nm), stream));
     HIP_TRY (hipMemcpyAsync (sums.data (), e->rssi_sum.p, nm * sizeof (uint64_t), hipMemcpyDeviceToHost, stream));
     HIP_TRY (hipStreamSynchronize (stream));
     for (size_t i = 0; i < nm; i++) {
@@ -604,6 +721,10 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   sp.short_tab = e->tabs.short_tab; sp.short_n = e->tabs.short_n; sp.long_tab = e->tabs.long_tab; sp.long_n = e->tabs.long_n;
   sp.lut256 = e->tabs.lut256; sp.bloom_short = e->tabs.bloom_short; sp.bloom_long = e->tabs.bloom_long;
   sp.crc_table = e->tabs.crc_table;
+  if (e->cfg.filter_dc) {
+    int rc_dc = prepare_dc (e, d_iq, nbytes, d_halo, stream, &sp);
+    if (rc_dc != MODES_OK) return rc_dc;
+  }
   q.T = T; q.nsteps = T / 8;
   q.bshift = 0; while ((1u << q.bshift) < B) q.bshift++;
   q.acc0 = 0; q.pending = 1;
@@ -716,8 +837,8 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
     if ((rc = e->rssi_sum.reserve (nr)) != MODES_OK) return rc;
     HIP_TRY (hipMemcpyAsync (e->rssi_pos.p, rpos.data (), nr * sizeof (uint64_t), hipMemcpyHostToDevice, stream));
     HIP_TRY (hipMemcpyAsync (e->rssi_len.p, rlen.data (), nr * sizeof (uint32_t), hipMemcpyHostToDevice, stream));
-    HIP_TRY (launch_rssi2400 (e->conv, sp.iq, sp.nsamples, sp.halo, sp.ov, sp.block_samples, sp.lut256, e->rssi_pos.p,
-                              e->rssi_len.p, e->rssi_sum.p, uint32_t (nr), stream));
+    HIP_TRY (launch_rssi2400 (sp.conv, sp.iq, sp.conv == kConvMagU16 ? sp.navail : sp.nsamples, sp.halo, sp.ov, sp.block_samples,
+                              sp.lut256, e->rssi_pos.p, e->rssi_len.p, e->rssi_sum.p, uint32_t (nr), stream));
     HIP_TRY (hipMemcpyAsync (sums.data (), e->rssi_sum.p, nr * sizeof (uint64_t), hipMemcpyDeviceToHost, stream));
     HIP_TRY (hipStreamSynchronize (stream));
     for (size_t i = 0; i < nr; i++)
@@ -806,6 +927,46 @@ size_t modes_engine_block_power (modes_engine *e, double *out, size_t max)
 }
 
 const uint16_t *modes_engine_tail_halo (const modes_engine *e) { return e ? e->tail.p : nullptr; }
+
+int modes_engine_set_dc_state (modes_engine *e, float z1_I, float z1_Q)
+{
+  if (!e) return fail (MODES_E_ARG, "null engine");
+  e->dc_z[0] = z1_I; e->dc_z[1] = z1_Q;
+  return MODES_OK;
+}
+
+int modes_engine_get_dc_state (const modes_engine *e, float *z1_I, float *z1_Q)
+{
+  if (!e || !z1_I || !z1_Q) return fail (MODES_E_ARG, "null argument");
+  *z1_I = e->dc_z[0]; *z1_Q = e->dc_z[1];
+  return MODES_OK;
+}
+
+int modes_engine_set_dc_lead (modes_engine *e, uint64_t lead_samples, uint64_t warm_samples)
+{
+  if (!e) return fail (MODES_E_ARG, "null engine");
+  e->dc_lead = lead_samples;
+  e->dc_warm = warm_samples;
+  return MODES_OK;
+}
+
+int modes_engine_get_dc_info (const modes_engine *e, modes_dc_info *out)
+{
+  if (!e || !out) return fail (MODES_E_ARG, "null argument");
+  *out = e->dc_info;
+  return MODES_OK;
+}
+
+const uint16_t *modes_engine_dc_magnitudes (const modes_engine *e) { return e && e->dc_mag.p ? e->dc_mag.p + 8 : nullptr; }
+
+int modes_engine_read_dc_magnitudes (modes_engine *e, uint16_t *out, size_t first, size_t count)
+{
+  if (!e || !out || !e->dc_mag.p) return fail (MODES_E_ARG, "no filter_dc run to read from");
+  if (first + count + 8 > e->dc_mag.cap) return fail (MODES_E_ARG, "range past the magnitude buffer");
+  HIP_TRY (hipSetDevice (e->cfg.device));
+  HIP_TRY (hipMemcpy (out, e->dc_mag.p + 8 + first, count * sizeof (uint16_t), hipMemcpyDeviceToHost));
+  return MODES_OK;
+}
 
 int modes_engine_halo_at (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t at_sample, uint16_t *d_out, void *stream_v)
 {

@@ -1021,10 +1021,10 @@ void emit2400_kernel (const EmitParams p)
       const int mbits = msg_bits_for_df (int (df));
       const int slen = mbits * 12 / 5;
       u64 acc = 0;                                  // ref: src/demod-2400.c:486-497
-      if (p.mode != 2000 && CONV != kConvMagU16) {
+      if (p.mode != 2000) {
         const long long n0 = (long long) P + 19 - (long long) p.ov;                     // first sample of the sum
         const bool lut = CONV == kConvUc8Lut || CONV == kConvUc8LutPower;
-        if (!lut && n0 >= 0 && uint64_t (n0) + 320 <= p.nsamples) {
+        if (!lut && CONV != kConvMagU16 && n0 >= 0 && uint64_t (n0) + 320 <= p.nsamples) {
           // inside the shard: the (at most) five loads of a lane are issued together
           uint32_t raw[5];
 #pragma unroll
@@ -1047,7 +1047,7 @@ void emit2400_kernel (const EmitParams p)
           }
         } else {
           for (int q = lane; q < slen; q += 64) {
-            const uint32_t m = mag_of_V<CONV> (p.iq, p.nsamples, p.halo, p.ov, p.block_samples, p.lut256, (long long) P + 19 + q);
+            const uint32_t m = mag_of_V<CONV> (p.iq, CONV == kConvMagU16 ? p.navail : p.nsamples, p.halo, p.ov, p.block_samples, p.lut256, (long long) P + 19 + q);
             acc += u64 (m * m);
           }
         }
@@ -1114,7 +1114,7 @@ void tail_kernel (const ScanParams p, uint64_t at, uint16_t *out)
 {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= p.ov) return;
-  out[i] = mag_of_V<CONV> (p.iq, p.nsamples, p.halo, p.ov, p.block_samples, p.lut256, (long long) (at + i));
+  out[i] = mag_of_V<CONV> (p.iq, CONV == kConvMagU16 ? p.navail : p.nsamples, p.halo, p.ov, p.block_samples, p.lut256, (long long) (at + i));
 }
 
 hipError_t launch_tail (const ScanParams &p, uint64_t at, uint16_t *out, hipStream_t stream)
@@ -1127,6 +1127,7 @@ hipError_t launch_tail (const ScanParams &p, uint64_t at, uint16_t *out, hipStre
     case kConvSc16Int:        hipLaunchKernelGGL (tail_kernel<kConvSc16Int>, grid, block, 0, stream, p, at, out); break;
     case kConvSc16Generic:    hipLaunchKernelGGL (tail_kernel<kConvSc16Generic>, grid, block, 0, stream, p, at, out); break;
     case kConvSc16Q11Generic: hipLaunchKernelGGL (tail_kernel<kConvSc16Q11Generic>, grid, block, 0, stream, p, at, out); break;
+    case kConvMagU16:         hipLaunchKernelGGL (tail_kernel<kConvMagU16>, grid, block, 0, stream, p, at, out); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError ();
@@ -1200,6 +1201,7 @@ hipError_t launch_rssi2400 (int conv, const uint8_t *iq, uint64_t nsamples, cons
     case kConvSc16Int:        RSSI (kConvSc16Int); break;
     case kConvSc16Generic:    RSSI (kConvSc16Generic); break;
     case kConvSc16Q11Generic: RSSI (kConvSc16Q11Generic); break;
+    case kConvMagU16:         RSSI (kConvMagU16); break;           // `nsamples` = magnitudes held by `iq`
     default: return hipErrorInvalidValue;
   }
 #undef RSSI
@@ -1292,6 +1294,7 @@ hipError_t launch_emit2400 (const EmitParams &p, hipStream_t stream)
     case kConvSc16Int:        hipLaunchKernelGGL (emit2400_kernel<kConvSc16Int>, grid, block, 0, stream, p); break;
     case kConvSc16Generic:    hipLaunchKernelGGL (emit2400_kernel<kConvSc16Generic>, grid, block, 0, stream, p); break;
     case kConvSc16Q11Generic: hipLaunchKernelGGL (emit2400_kernel<kConvSc16Q11Generic>, grid, block, 0, stream, p); break;
+    case kConvMagU16:         hipLaunchKernelGGL (emit2400_kernel<kConvMagU16>, grid, block, 0, stream, p); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError ();

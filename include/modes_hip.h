@@ -232,6 +232,33 @@ size_t               modes_engine_block_power (modes_engine *e, double *out, siz
 /* the last block's trailing `overlap` magnitudes (device memory), to pass as d_halo of the next shard */
 const uint16_t      *modes_engine_tail_halo (const modes_engine *e);
 
+/* ---- float converters with the DC block on (filter_dc = 1; ref: src/convert.c:112-245) ----
+ * The filter state z1_I / z1_Q of convert_state runs through the whole stream.  An engine keeps it between runs the
+ * way convert_state does between convert_func calls (a new engine starts at 0, 0); set it to decode another stream.
+ * d_iq must be 16-byte aligned. */
+int  modes_engine_set_dc_state (modes_engine *e, float z1_I, float z1_Q);
+int  modes_engine_get_dc_state (const modes_engine *e, float *z1_I, float *z1_Q);
+/* For shards decoded in parallel: tells the NEXT run that d_iq[0] is preceded in device memory by `lead_samples`
+ * (a multiple of 256) valid samples of the same stream and that the filter state in front of them is unknown.  The
+ * filter is then settled on the lead-in: the run fails with MODES_E_ARG if it is too short to do so (about
+ * 35 / DC_A samples are needed: 13.4 M at 2.4 MS/s).  A lead-in that covers the overlap also replaces d_halo.
+ * warm_samples != 0 overrides the warm-up length chunks inside a run use (a performance knob: results do not
+ * depend on it); 0 = default. */
+int  modes_engine_set_dc_lead (modes_engine *e, uint64_t lead_samples, uint64_t warm_samples);
+typedef struct modes_dc_info {
+  uint32_t chunks;           /* independent chains of the last run                            */
+  uint32_t rerun_chunks;     /* chunks re-run from the exact end state of their predecessor   */
+  uint64_t chunk_samples, warm_samples;
+  float    chain_ms;         /* duration of the chain kernel (HIP events on the launch stream) */
+  uint32_t reserved;
+} modes_dc_info;
+int  modes_engine_get_dc_info (const modes_engine *e, modes_dc_info *out);
+/* The magnitudes of the last filter_dc run in device memory: `overlap` entries in front of the shard's first sample,
+ * then one per sample (what convert_func wrote into the mag_bufs, back to back). */
+const uint16_t *modes_engine_dc_magnitudes (const modes_engine *e);
+/* ... `count` of them starting at entry `first`, copied to host memory */
+int  modes_engine_read_dc_magnitudes (modes_engine *e, uint16_t *out, size_t first, size_t count);
+
 /* The `overlap` magnitudes that precede sample `at_sample` of the IQ in d_iq (zeros before sample 0), written to
  * d_out (device): the d_halo of a shard that starts at `at_sample`, for callers that decode shards in parallel and so
  * cannot wait for the previous shard's tail.  at_sample must be a multiple of the block length. */

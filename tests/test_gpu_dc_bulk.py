@@ -1,0 +1,137 @@
+"""GPU parity: the float converters with the DC block ON through the bulk engine (filter_dc=1), against the oracle.
+
+The reference's shipped configuration (`DC-filter = true`, dump1090.cfg:101) selects convert_uc8_generic /
+convert_sc16_generic (ref: src/convert.c:301-308, 112-200): the one-pole filter runs through the whole stream, so
+the magnitudes of every sample -- not only the messages -- must equal the sequential result bit for bit."""
+import numpy as np
+import pytest
+
+import dump1090_amd as da
+from dump1090_amd import synth
+from oracle import orc
+from util import assert_same_messages, oracle_run
+
+pytestmark = pytest.mark.gpu
+FMT = {"uc8": da.INPUT_UC8, "sc16": da.INPUT_SC16, "sc16q11": da.INPUT_SC16Q11}
+CONV = {"uc8": 2, "sc16": 4, "sc16q11": 5}
+OV = {2000000: 272, 2400000: 326, 8000000: 1088}
+
+
+def oracle_mags(iq, fmt, rate):
+    n = iq.size // 2
+    mag, _, st = orc.convert(CONV[fmt], iq, n, sample_rate=float(rate), filter_dc=True)
+    return mag, (st.z1_I, st.z1_Q)
+
+
+def check_run(iq, fmt, rate, warm=0, expect_min_msgs=1, fix_bits=1):
+    e = da.Engine(rate, FMT[fmt], filter_dc=True, compute_power=True, fix_bits=fix_bits)
+    if warm:
+        e.set_dc_lead(0, warm)
+    e.run_host(iq)
+    n = iq.size // 2
+    ov = OV[rate]
+    got = e.dc_magnitudes(0, ov + n)
+    exp, zexp = oracle_mags(iq, fmt, rate)
+    assert not got[:ov].any()                                   # the stream's first block is preceded by zeros
+    bad = np.flatnonzero(got[ov:] != exp)
+    assert bad.size == 0, "first differing sample %d of %d (%d differ)" % (bad[0], n, bad.size)
+    assert e.get_dc_state() == zexp
+    emsg, est = oracle_run(iq, fmt, rate=rate, filter_dc=True, compute_power=True, fix_bits=fix_bits)
+    assert len(emsg) >= expect_min_msgs
+    assert_same_messages(e.messages(), emsg)
+    return e
+
+
+def test_modes1_2000_generic_dc(modes1):
+    """The reference's own recording at its native rate: 259 messages."""
+    e = check_run(modes1, "uc8", 2000000, expect_min_msgs=259)
+    assert e.num_messages() == 259
+
+
+def test_modes1_2400_generic_dc(modes1):
+    e = da.Engine(2400000, da.INPUT_UC8, filter_dc=True, compute_power=True)
+    e.run_host(modes1)
+    _, est = oracle_run(modes1, "uc8", filter_dc=True, compute_power=True)
+    assert e.stats()["valid_preamble"] == est["valid_preamble"] == 2956
+
+
+@pytest.mark.parametrize("fmt", ["uc8", "sc16", "sc16q11"])
+def test_synthetic_with_dc_offset(fmt):
+    iq, _ = synth.capture(1_500_000, 2.4e6, fmt, seed=31, frames_per_sec=1500, dc_offset=0.021 - 0.013j,
+                          min_amp_db=-20 if fmt == "sc16q11" else -32)
+    check_run(iq, fmt, 2400000, expect_min_msgs=200)
+
+
+@pytest.mark.parametrize("warm", [256, 4096, 262144])
+def test_short_warmup_is_repaired(warm):
+    """With a warm-up far too short for the brackets to close, every chunk is re-run from its predecessor's exact
+    end state: the result must not depend on the warm-up length."""
+    iq, _ = synth.capture(700_000, 2.4e6, "uc8", seed=32, frames_per_sec=1500, dc_offset=-0.01 + 0.03j)
+    e = check_run(iq, "uc8", 2400000, warm=warm, expect_min_msgs=100)
+    info = e.dc_info()
+    assert info["chunks"] >= 8 and info["warm_samples"] == warm
+    assert info["rerun_chunks"] >= info["chunks"] - 1 - (warm + info["chunk_samples"] - 1) // info["chunk_samples"]
+
+
+@pytest.mark.parametrize("nsamples", [0, 1, 255, 256, 257, 4099, 65536, 131072 + 331])
+def test_ragged_lengths(nsamples):
+    iq, _ = synth.capture(max(nsamples, 1), 2.4e6, "uc8", seed=33, frames_per_sec=3000, min_amp_db=-12, dc_offset=0.02)
+    iq = iq[: 2 * nsamples]
+    check_run(iq, "uc8", 2400000, expect_min_msgs=0)
+
+
+def test_state_carries_between_runs():
+    """Two runs on consecutive pieces of one stream = one run (convert_state persists between calls)."""
+    iq, _ = synth.capture(131072 * 5, 2.4e6, "uc8", seed=34, frames_per_sec=1500, dc_offset=0.015 + 0.02j)
+    exp, zexp = oracle_mags(iq, "uc8", 2400000)
+    cut = 131072 * 2
+    e = da.Engine(2400000, da.INPUT_UC8, filter_dc=True, compute_power=True)
+    e.run_host(iq[: 2 * cut])
+    a = e.dc_magnitudes(326, cut)
+    e.run_host(iq[2 * cut:], first_sample=cut)
+    b = e.dc_magnitudes(326, iq.size // 2 - cut)
+    assert np.array_equal(np.concatenate([a, b]), exp)
+    assert e.get_dc_state() == zexp
+
+
+def test_demod_8000_behind_dc_converter():
+    iq, _ = synth.capture(8_000_00, 8e6, "sc16", seed=35, frames_per_sec=2500, dc_offset=0.01 - 0.02j)
+    check_run(iq, "sc16", 8000000, expect_min_msgs=50)
+
+
+def test_long_recording_brackets_close():
+    """40 M samples at 2.4 MS/s: chunks beyond ~13.4 M samples start from the bracket [-1, 1] and must have
+    closed on the reference's exact state by their first sample."""
+    import torch
+    from dump1090_amd import synth_torch
+    n = 40_000_000
+    iq_t, _ = synth_torch.capture_gpu(n, 2.4e6, "uc8", seed=36, frames_per_sec=800.0, dc_offset=(0.011, -0.017))
+    iq = iq_t.cpu().numpy()
+    e = da.Engine(2400000, da.INPUT_UC8, filter_dc=True, compute_power=True)
+    e.run_device(iq_t.data_ptr(), iq.nbytes)
+    torch.cuda.synchronize()
+    info = e.dc_info()
+    exp, zexp = oracle_mags(iq, "uc8", 2400000)
+    got = e.dc_magnitudes(326, n)
+    bad = np.flatnonzero(got != exp)
+    assert bad.size == 0, "first differing sample %d (%d differ); %r" % (bad[0], bad.size, info)
+    assert e.get_dc_state() == zexp
+    assert info["chunks"] > 300 and info["rerun_chunks"] <= 2, info
+    emsg, _ = oracle_run(iq, "uc8", filter_dc=True, compute_power=True)
+    assert len(emsg) > 5000
+    assert_same_messages(e.messages(), emsg)
+
+    # a shard decoded on its own: 14 M samples of lead-in settle the filter, the lead-in also yields the overlap
+    first = 153 * 131072
+    lead = 14_000_128
+    s = da.Engine(2400000, da.INPUT_UC8, filter_dc=True, compute_power=True)
+    s.set_dc_lead(lead)
+    s.run_device(iq_t.data_ptr() + 2 * first, iq.nbytes - 2 * first, first_sample=first)
+    got = s.dc_magnitudes(0, 326 + n - first)
+    assert np.array_equal(got, exp[first - 326:])
+    assert s.get_dc_state() == zexp
+
+    # ... and a lead-in that is too short is refused, not guessed
+    s.set_dc_lead(65536)
+    with pytest.raises(da.ModesError):
+        s.run_device(iq_t.data_ptr() + 2 * first, iq.nbytes - 2 * first, first_sample=first)
