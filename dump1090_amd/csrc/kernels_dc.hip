@@ -111,17 +111,28 @@ void dc_chain_kernel (const DcParams p)
       const float *t = s_t[ch];
       float *zo = s_z[lane];
       if (cnt == kDcBatch) {
-        float4 v = *reinterpret_cast<const float4 *> (t);
-#pragma unroll 4
-        for (int i = 0; i < kDcBatch; i += 4) {
-          const float4 nx = *reinterpret_cast<const float4 *> (t + ((i + 4) & (kDcBatch - 1)));
-          float4 o;
-          z = __fadd_rn (v.x, __fmul_rn (z, B)); o.x = z;          // ref: src/convert.c:137-140 (one rounding per operation)
-          z = __fadd_rn (v.y, __fmul_rn (z, B)); o.y = z;
-          z = __fadd_rn (v.z, __fmul_rn (z, B)); o.z = z;
-          z = __fadd_rn (v.w, __fmul_rn (z, B)); o.w = z;
-          if (region) *reinterpret_cast<float4 *> (zo + i) = o;
-          v = nx;
+        // 32 samples at a time: their eight LDS reads are in flight while the 32 before them are stepped
+        constexpr int G = 8;                        // float4 per group
+        float4 cur[G], nxt[G];
+#pragma unroll
+        for (int k = 0; k < G; k++) cur[k] = *reinterpret_cast<const float4 *> (t + 4 * k);
+#pragma unroll
+        for (int g = 0; g < kDcBatch / (4 * G); g++) {
+          if (g + 1 < kDcBatch / (4 * G)) {
+#pragma unroll
+            for (int k = 0; k < G; k++) nxt[k] = *reinterpret_cast<const float4 *> (t + 4 * G * (g + 1) + 4 * k);
+          }
+#pragma unroll
+          for (int k = 0; k < G; k++) {
+            float4 o;
+            z = __fadd_rn (cur[k].x, __fmul_rn (z, B)); o.x = z;       // ref: src/convert.c:137-140 (one rounding per operation)
+            z = __fadd_rn (cur[k].y, __fmul_rn (z, B)); o.y = z;
+            z = __fadd_rn (cur[k].z, __fmul_rn (z, B)); o.z = z;
+            z = __fadd_rn (cur[k].w, __fmul_rn (z, B)); o.w = z;
+            *reinterpret_cast<float4 *> (zo + 4 * G * g + 4 * k) = o;
+          }
+#pragma unroll
+          for (int k = 0; k < G; k++) cur[k] = nxt[k];
         }
       } else {
         for (int i = 0; i < cnt; i++) { z = __fadd_rn (t[i], __fmul_rn (z, B)); zo[i] = z; }
