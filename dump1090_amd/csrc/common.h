@@ -175,19 +175,22 @@ struct D8Params {
 // ---- float converters with the DC block on, whole recording (kernels_dc.hip) ----------------
 // One chain of the filter per chunk: it starts at sample `start` (<= the chunk's first sample, may reach back
 // into the lead-in in front of the shard) from the bracket [lo, hi] per channel; lo == hi when the state is known.
+constexpr int kDcBatch = 4096;         // samples a workgroup stages per round: sixteen per thread
 struct DcChunk { long long start; float zIlo, zIhi, zQlo, zQhi; uint32_t chunk; uint32_t pad; };
 static_assert(sizeof(DcChunk) == 32, "DcChunk must be 32 bytes");
 
 struct DcParams {
   const uint8_t  *iq;          // sample 0 of the shard (16-byte aligned); `start` may be negative
   uint64_t        n;           // samples in the shard
-  uint64_t        chunk_len;   // samples per chunk, a multiple of 256
+  uint64_t        chunk_len;   // samples per chunk, a multiple of kDcBatch
   float           A, B;        // convert_state.DC_A, DC_B (ref: src/convert.c:349-353)
   const DcChunk  *desc;        // one per launched wave
   uint16_t       *mag;         // [n] magnitudes of the shard's samples (4-byte aligned)
   float          *z_start;     // [nchunks][4] I-lo, I-hi, Q-lo, Q-hi in front of the chunk's first sample
   float          *z_end;       // [nchunks][2] z1_I, z1_Q behind the chunk's last sample
   uint32_t       *unmerged;    // [nchunks] 1 = the bracket was still open at the chunk's first sample
+  unsigned long long *ticks;   // [nchunks][16] profiling aid (wave 0: lifetime in clock ticks, guess rounds, plain rounds, ticks in the chain, at barriers); may be null
+  unsigned long long *rounds;  // [2] guess rounds (256 samples tried), plain rounds (64 samples stepped one by one); may be null
 };
 
 struct EmitParams {

@@ -40,14 +40,31 @@ __device__ __forceinline__ uint16_t mag_sc16_int (int i16, int q16)
 {
   return uint16_t (mag_sc16_abs (uint32_t (i16 < 0 ? -i16 : i16), uint32_t (q16 < 0 ? -q16 : q16)));
 }
-// one IQ pair as it lies in memory (I in the low half): |.| of both halves with two packed operations
+// one IQ pair as it lies in memory (I in the low half): |.| of both halves with two packed operations, then the
+// selected linear form as ONE packed dot product: the four forms are (cI, cQ) pairs, chosen by (I < Q) and
+// (I < threshold); result = (cI * |I| + cQ * |Q|) >> 16 (at most 91488 * 32768 < 2^32).  Returns the 32-bit sum:
+// the magnitude is its high half.
 typedef short short2v __attribute__ ((ext_vector_type (2)));
-__device__ __forceinline__ uint32_t mag_sc16_word (uint32_t d)
+typedef unsigned short ushort2v __attribute__ ((ext_vector_type (2)));
+__device__ __forceinline__ uint32_t mag_sc16_sum (uint32_t d)
 {
   const short2v v = __builtin_bit_cast (short2v, d);
   const short2v a = __builtin_elementwise_max (v, short2v (-v));      // -32768 stays 0x8000 = 32768 unsigned
   const uint32_t u = __builtin_bit_cast (uint32_t, a);
-  return mag_sc16_abs (u & 0xFFFFu, u >> 16);
+  const uint32_t I = u & 0xFFFFu, Q = u >> 16;
+  const bool lt = I < Q;
+  const uint32_t t = __umul24 (lt ? 106u : 618u, Q) >> 8;
+  const bool sel = lt == (I < t);
+  const uint32_t k_sel = lt ? (12868u | (64692u << 16)) : (64692u | (12868u << 16));
+  const uint32_t k_not = lt ? (36646u | (54842u << 16)) : (54842u | (36646u << 16));
+  const uint32_t k = sel ? k_sel : k_not;
+  return __builtin_amdgcn_udot2 (__builtin_bit_cast (ushort2v, u), __builtin_bit_cast (ushort2v, k), 0u, false);
+}
+__device__ __forceinline__ uint32_t mag_sc16_word (uint32_t d) { return mag_sc16_sum (d) >> 16; }
+// magnitudes of two IQ pairs packed as they lie in a magnitude buffer (first sample in the low half)
+__device__ __forceinline__ uint32_t mag_sc16_pair (uint32_t d0, uint32_t d1)
+{
+  return __builtin_amdgcn_perm (mag_sc16_sum (d1), mag_sc16_sum (d0), 0x07060302u);
 }
 
 // ref: src/convert.c:142-147 -- the tail shared by the three float converters, DC block already applied
@@ -175,8 +192,9 @@ __device__ __forceinline__ void load_raw8 (const ScanParams &p, long long n0, ui
 {
   if (CONV == kConvUc8Lut || CONV == kConvUc8LutPower) {
     // as written: output sample i of a block reads input BYTE i of that block (ref: src/convert.c:19,29)
-    const uint64_t blk = uint64_t (n0) / p.block_samples, i = uint64_t (n0) % p.block_samples;
-    const uint2 v = *reinterpret_cast<const uint2 *> (p.iq + blk * 2 * p.block_samples + i);
+    // block_samples is a power of two (256 KiB / bytes per sample): byte offset = 2 * block start + offset in block
+    const uint64_t in_blk = uint64_t (n0) & uint64_t (p.block_samples - 1);
+    const uint2 v = *reinterpret_cast<const uint2 *> (p.iq + 2 * (uint64_t (n0) - in_blk) + in_blk);
     d[0] = v.x; d[1] = v.y;
   } else if (CONV == kConvUc8Generic || CONV == kConvMagU16) {
     const uint4 v = *reinterpret_cast<const uint4 *> (p.iq + 2 * n0);
@@ -192,6 +210,12 @@ template <int CONV>
 __device__ __forceinline__ uint4 convert_raw8 (const uint16_t *lut, const uint32_t *d)
 {
   if (CONV == kConvMagU16) { uint4 pk; pk.x = d[0]; pk.y = d[1]; pk.z = d[2]; pk.w = d[3]; return pk; }
+  if (CONV == kConvSc16Int) {
+    uint4 pk;
+    pk.x = mag_sc16_pair (d[0], d[1]); pk.y = mag_sc16_pair (d[2], d[3]);
+    pk.z = mag_sc16_pair (d[4], d[5]); pk.w = mag_sc16_pair (d[6], d[7]);
+    return pk;
+  }
   uint16_t out[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) {

@@ -217,6 +217,7 @@ int fill_scan_params (modes_engine *e, const void *d_iq, size_t nbytes, const ui
   if ((rc = e->counts.reserve (nstrips)) != MODES_OK) return rc;
   if ((rc = e->vp_counts.reserve (nstrips)) != MODES_OK) return rc;
   if ((rc = e->vp_bitmap.reserve (size_t (nstrips) * kWords)) != MODES_OK) return rc;
+  if (e->block_samples & (e->block_samples - 1)) return fail (MODES_E_ARG, "block length %u is not a power of two", e->block_samples);
   memset (sp, 0, sizeof *sp);
   sp->iq = static_cast<const uint8_t *> (d_iq);
   sp->nsamples = nsamples;
@@ -275,14 +276,16 @@ int prepare_dc (modes_engine *e, const void *d_iq, size_t nbytes, const uint16_t
   sp->halo = nullptr;
   if (n == 0) return MODES_OK;
 
-  const uint64_t n_eff = n + back, lead_eff = (lead - back) & ~255ull;   // chains start on the 256-sample grid of the shard
+  const uint64_t n_eff = n + back, lead_eff = (lead - back) / kDcBatch * kDcBatch;   // chains start on the batch grid of the shard
   uint64_t K = n_eff / 65536;
   if (K < 1) K = 1;
-  if (K > 1024) K = 1024;
-  const uint64_t L = ((n_eff + K - 1) / K + 255) / 256 * 256;
+  uint64_t kmax = 256;                                                // one workgroup (four chains) per CU: the chains are issue-bound
+  if (const char *ev = getenv ("MODES_DC_CHUNKS")) kmax = uint64_t (atoll (ev)) ? uint64_t (atoll (ev)) : kmax;
+  if (K > kmax) K = kmax;
+  const uint64_t L = ((n_eff + K - 1) / K + kDcBatch - 1) / kDcBatch * kDcBatch;
   K = (n_eff + L - 1) / L;
   uint64_t warm = e->dc_warm ? e->dc_warm : uint64_t (std::ceil (35.0 / double (e->dc_A)));
-  warm = (warm + 255) / 256 * 256;
+  warm = (warm + kDcBatch - 1) / kDcBatch * kDcBatch;
   const float bound = e->conv == kConvSc16Q11Generic ? 16.0f : 1.0f;  // |f| never exceeds it, so neither does |z1|
   std::vector<DcChunk> desc (K);
   for (uint64_t c = 0; c < K; c++) {
@@ -301,13 +304,18 @@ int prepare_dc (modes_engine *e, const void *d_iq, size_t nbytes, const uint16_t
   if ((rc = e->dc_desc.reserve (K + 1)) != MODES_OK) return rc;
   if ((rc = e->dc_zs.reserve (4 * K)) != MODES_OK) return rc;
   if ((rc = e->dc_ze.reserve (2 * K)) != MODES_OK) return rc;
-  if ((rc = e->dc_unm.reserve (K)) != MODES_OK) return rc;
+  if ((rc = e->dc_unm.reserve (K + 16)) != MODES_OK) return rc;
   DcParams q;
   memset (&q, 0, sizeof q);
   q.iq = static_cast<const uint8_t *> (d_iq) - back * bps;
   q.n = n_eff; q.chunk_len = L; q.A = e->dc_A; q.B = e->dc_B;
   q.desc = e->dc_desc.p; q.mag = V + ov - back;
   q.z_start = e->dc_zs.p; q.z_end = e->dc_ze.p; q.unmerged = e->dc_unm.p;
+  q.rounds = reinterpret_cast<unsigned long long *> (e->dc_unm.p + ((K + 1) & ~1ull));
+  HIP_TRY (hipMemsetAsync (q.rounds, 0, 6 * sizeof (unsigned long long), stream));
+  unsigned long long *d_ticks = nullptr;
+  if (getenv ("MODES_DC_PROFILE")) { HIP_TRY (hipMalloc (reinterpret_cast<void **> (&d_ticks), 16 * K * sizeof (unsigned long long))); HIP_TRY (hipMemset (d_ticks, 0, 16 * K * sizeof (unsigned long long))); }
+  q.ticks = d_ticks;
   hipEvent_t ea, eb;
   HIP_TRY (hipEventCreate (&ea));
   HIP_TRY (hipEventCreate (&eb));
@@ -320,11 +328,34 @@ int prepare_dc (modes_engine *e, const void *d_iq, size_t nbytes, const uint16_t
   HIP_TRY (hipMemcpyAsync (zs.data (), e->dc_zs.p, 4 * K * sizeof (float), hipMemcpyDeviceToHost, stream));
   HIP_TRY (hipMemcpyAsync (ze.data (), e->dc_ze.p, 2 * K * sizeof (float), hipMemcpyDeviceToHost, stream));
   HIP_TRY (hipMemcpyAsync (unm.data (), e->dc_unm.p, K * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
+  unsigned long long rounds[6] = { 0, 0, 0, 0, 0, 0 };
+  HIP_TRY (hipMemcpyAsync (rounds, q.rounds, sizeof rounds, hipMemcpyDeviceToHost, stream));
   HIP_TRY (hipStreamSynchronize (stream));
   (void) hipEventElapsedTime (&e->dc_info.chain_ms, ea, eb);
   (void) hipEventDestroy (ea);
   (void) hipEventDestroy (eb);
   e->dc_info.chunks = uint32_t (K); e->dc_info.chunk_samples = L; e->dc_info.warm_samples = warm;
+  e->dc_info.guess_rounds = rounds[0]; e->dc_info.plain_rounds = rounds[1];
+  if (d_ticks) {
+    std::vector<unsigned long long> tk (16 * K);
+    HIP_TRY (hipMemcpy (tk.data (), d_ticks, 16 * K * sizeof (unsigned long long), hipMemcpyDeviceToHost));
+    (void) hipFree (d_ticks);
+    std::vector<uint64_t> order (K);
+    for (uint64_t c = 0; c < K; c++) order[c] = c;
+    std::sort (order.begin (), order.end (), [&] (uint64_t a, uint64_t b) { return tk[16 * a] > tk[16 * b]; });
+    for (uint64_t i = 0; i < K && i < 12; i++) {
+      const uint64_t c = order[i];
+      fprintf (stderr, "  slowest: chunk %4llu: %9llu ticks, %7llu guesses, %6llu plain, chain %llu, barriers %llu; guesses/plain per wave %llu/%llu %llu/%llu %llu/%llu %llu/%llu\n", (unsigned long long) c, tk[16 * c], tk[16 * c + 1], tk[16 * c + 2], tk[16 * c + 3], tk[16 * c + 4],
+               tk[16 * c + 5], tk[16 * c + 6], tk[16 * c + 7], tk[16 * c + 8], tk[16 * c + 9], tk[16 * c + 10], tk[16 * c + 11], tk[16 * c + 12]);
+    }
+    for (uint64_t c = 0; c < K; c += (K > 16 ? K / 16 : 1))
+      fprintf (stderr, "  chunk %4llu: %9llu ticks, %7llu guesses, %6llu plain, %lld steps\n", (unsigned long long) c, tk[16 * c], tk[16 * c + 1], tk[16 * c + 2],
+               (long long) std::min (n_eff, (c + 1) * L) - desc[c].start);
+  }
+  if (getenv ("MODES_DC_PROFILE")) fprintf (stderr, "dc profile (wave 0 sums over %llu chunks): chain %llu barrier %llu total %llu ticks, longest %llu\n", (unsigned long long) K, rounds[2], rounds[3], rounds[4], rounds[5]);
+  for (uint64_t c = 0; c < K; c++) e->dc_info.chain_steps += 2 * uint64_t ((long long) std::min (n_eff, (c + 1) * L) - desc[c].start);
+  q.rounds = nullptr;
+  q.ticks = nullptr;
   if (unm[0]) return fail (MODES_E_ARG, "filter_dc: a lead-in of %llu samples does not settle the DC filter (about %llu needed)",
                            (unsigned long long) lead, (unsigned long long) warm);
   for (uint64_t c = 1; c < K; c++) {

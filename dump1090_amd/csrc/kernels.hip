@@ -13,6 +13,9 @@
 #include "device_common.h"
 #include "kernels.h"
 
+#ifndef SCAN_WAVES
+#define SCAN_WAVES 6
+#endif
 namespace modes {
 
 
@@ -75,7 +78,7 @@ __device__ __forceinline__ uint32_t wave_xor_to63 (uint32_t v)
 // the scan kernel
 // ------------------------------------------------------------------------------------------
 template <int CONV, bool PE>
-__global__ __launch_bounds__ (64 * kWavesPerBlock)
+__global__ __launch_bounds__ (64 * kWavesPerBlock) __attribute__ ((amdgpu_waves_per_eu (SCAN_WAVES, SCAN_WAVES)))
 void scan2400_kernel (const ScanParams p)
 {
   constexpr bool kLut = CONV == kConvUc8Lut || CONV == kConvUc8LutPower;

@@ -10,10 +10,18 @@
 // A chunk of the stream therefore starts its chain `warm` samples early from a bracket lo <= z <= hi that
 // is known to hold the true state (|z1| never exceeds the largest |f|), steps lo and hi through the very
 // float operations of the reference, and once lo == hi the value IS the reference's z1 -- whatever the
-// start was.  Chunks are independent; one wave runs one chunk: lanes 0..3 carry I-lo, I-hi, Q-lo, Q-hi,
-// all 64 lanes fetch/convert samples ahead of the chain and form the magnitudes behind it.
+// start was.  Chunks are independent; one workgroup of four waves runs one chunk, wave w one of the four chains
+// I-lo, I-hi, Q-lo, Q-hi (the hi waves idle once their bracket has closed); all 256 threads fetch/convert the next
+// 4096 samples and form the magnitudes behind the chains.
 // A chunk whose bracket has not closed at its first sample is reported (`unmerged`) and re-run by the
 // host from the exact end state of the chunk before it.
+//
+// A chain is a latency problem: two dependent operations per sample.  A wave therefore steps 1024 samples at once on
+// a GUESS and keeps what it can prove.  While z1 stays inside one binade and RN (z*B) keeps the same distance r to z,
+// every step adds an integer number of ulps:  z[k] = z0 + sum_{i<=k} (RN_ulp (t[i]) - r)  -- a prefix sum over the
+// lanes.  Lane k then performs the REAL step from the guessed z[k-1] and compares bit for bit with the guessed z[k]:
+// up to the first lane that disagrees the guesses are the reference's values by induction, and that lane's real
+// step is the next exact value.  Where guesses keep failing (z1 near zero) the wave falls back to plain steps.
 //
 // "ref:" citations are relative to the reference's root.
 #include <hip/hip_runtime.h>
@@ -24,7 +32,6 @@
 
 namespace modes {
 
-constexpr int kDcBatch = 256;          // samples per step of the wave: four per lane
 
 // raw IQ of four consecutive samples
 template <int CONV> struct DcRaw { uint32_t w[CONV == kConvUc8Generic ? 2 : 4]; };
@@ -63,111 +70,243 @@ __device__ __forceinline__ void dc_to_float (const DcRaw<CONV> &r, const float *
   }
 }
 
+
+// inclusive float prefix sum over the 64 lanes (row_shr 1,2,4,8, row_bcast:15, row_bcast:31; zero fill)
+__device__ __forceinline__ float wave_incl_scan_f (float v)
+{
+#define DCADD(CTRL, MASK, BOUND) v = __fadd_rn (v, __uint_as_float (dpp_mov<CTRL, MASK, BOUND> (__float_as_uint (v))))
+  DCADD (0x111, 0xF, true); DCADD (0x112, 0xF, true); DCADD (0x114, 0xF, true); DCADD (0x118, 0xF, true);
+  DCADD (0x142, 0xA, false); DCADD (0x143, 0xC, false);
+#undef DCADD
+  return v;
+}
+
+constexpr int kDcPer = 16;                      // consecutive samples per lane in one guess
+constexpr int kDcRound = 64 * kDcPer;           // samples per guess
+
+__device__ __forceinline__ float bcast_lane (float x, int l)
+{
+  return __uint_as_float (uint32_t (__builtin_amdgcn_readlane (int (__float_as_uint (x)), l)));
+}
+
+// The guess for kDcRound samples, kDcPer consecutive ones per lane: tk[q] = t of sample kDcPer * lane + q (only the
+// first m samples exist).  zt[q] = guessed z1 behind that sample, v[q] = the real step from the guessed predecessor
+// (ref: src/convert.c:137-140).  Returns the OR of v ^ zt over the lane's existing samples: 0 = every guess holds.
+template <bool WHOLE>
+__device__ __forceinline__ uint32_t dc_guess (const float *tk, int m, float z0, float B, int lane, float *zt, float *v)
+{
+  const float r = __fsub_rn (z0, __fmul_rn (z0, B));             // what the product takes off z0
+  const float c1 = __fadd_rn (z0, r);
+  float pf[kDcPer];                                              // inclusive sums of the lane's own increments, in ulps of z0
+#pragma unroll
+  for (int q = 0; q < kDcPer; q++) {
+    const float dq = __fsub_rn (__fadd_rn (z0, tk[q]), c1);      // (t rounded to z0's grid) - r
+    pf[q] = q ? __fadd_rn (pf[q - 1], dq) : dq;
+  }
+  const float incl = wave_incl_scan_f (pf[kDcPer - 1]);
+  float ex = __uint_as_float (dpp_mov<0x138, 0xF, true> (__float_as_uint (incl)));        // wave_shr:1: sum of the lanes below
+  if (lane == 0) ex = 0.0f;
+  const float zp0 = __fadd_rn (z0, ex);
+#pragma unroll
+  for (int q = 0; q < kDcPer; q++) zt[q] = __fadd_rn (zp0, pf[q]);
+  // the predecessor of the lane's first sample is the guess the lane below makes for its last one, bit for bit
+  // (not zp0: the two only agree while every sum above is exact) -- the induction over the samples rests on it
+  float zprev = __uint_as_float (dpp_mov<0x138, 0xF, true> (__float_as_uint (zt[kDcPer - 1])));
+  if (lane == 0) zprev = z0;
+  uint32_t acc = 0;
+#pragma unroll
+  for (int q = 0; q < kDcPer; q++) {
+    v[q] = __fadd_rn (tk[q], __fmul_rn (q ? zt[q - 1] : zprev, B));
+    const uint32_t x = __float_as_uint (v[q]) ^ __float_as_uint (zt[q]);
+    acc |= (WHOLE || kDcPer * lane + q < m) ? x : 0u;
+  }
+  return acc;
+}
+
+// One chain over t[0 .. cnt): returns z1 behind the last sample, zo[i] = z1 behind sample i.  z0 is uniform.
+// t and zo are 16-byte aligned.
+__device__ __forceinline__ float dc_chain_batch (const float *t, float *zo, int cnt, float z0, float B, int lane, uint32_t &n_guess, uint32_t &n_plain, int &backoff)
+{
+  int base = 0, plain = 0;
+  while (base < cnt) {
+    const int rem = cnt - base;
+    if (plain) {                                  // plain steps (ref: src/convert.c:137-140), then guess again
+      int m = 64 * plain;
+      if (m > rem) m = rem;
+      float z = z0;
+      if (lane == 0) {
+        int i = 0;
+        for (; i < m && ((base + i) & 3); i++) { z = __fadd_rn (t[base + i], __fmul_rn (z, B)); zo[base + i] = z; }
+        float4 nx = i + 4 <= m ? *reinterpret_cast<const float4 *> (t + base + i) : make_float4 (0.0f, 0.0f, 0.0f, 0.0f);
+        for (; i + 4 <= m; i += 4) {
+          const float4 x = nx;
+          if (i + 8 <= m) nx = *reinterpret_cast<const float4 *> (t + base + i + 4);      // in flight behind the four steps
+          float4 o;
+          z = __fadd_rn (x.x, __fmul_rn (z, B)); o.x = z;
+          z = __fadd_rn (x.y, __fmul_rn (z, B)); o.y = z;
+          z = __fadd_rn (x.z, __fmul_rn (z, B)); o.z = z;
+          z = __fadd_rn (x.w, __fmul_rn (z, B)); o.w = z;
+          *reinterpret_cast<float4 *> (zo + base + i) = o;
+        }
+        for (; i < m; i++) { z = __fadd_rn (t[base + i], __fmul_rn (z, B)); zo[base + i] = z; }
+      }
+      z0 = __uint_as_float (uint32_t (__builtin_amdgcn_readfirstlane (int (__float_as_uint (z)))));
+      base += m; n_plain += uint32_t (plain); plain = 0;
+      continue;
+    }
+    n_guess++;
+    float tk[kDcPer], zt[kDcPer], v[kDcPer];
+    const bool whole = rem >= kDcRound && !(base & 3);
+    int m = rem < kDcRound ? rem : kDcRound;
+    if ((base & 3) && m > kDcRound - (base & 3)) m = kDcRound - (base & 3);       // end on the 16-byte grid again
+    uint32_t acc;
+    if (whole) {                                  // the common round: aligned 16-byte LDS accesses
+      const float4 *src = reinterpret_cast<const float4 *> (t + base + kDcPer * lane);
+#pragma unroll
+      for (int g = 0; g < kDcPer / 4; g++) { const float4 x = src[g]; tk[4 * g] = x.x; tk[4 * g + 1] = x.y; tk[4 * g + 2] = x.z; tk[4 * g + 3] = x.w; }
+      acc = dc_guess<true> (tk, m, z0, B, lane, zt, v);
+    } else {                                      // the ragged end of the batch, or a start off the 16-byte grid
+#pragma unroll
+      for (int q = 0; q < kDcPer; q++) tk[q] = kDcPer * lane + q < m ? t[base + kDcPer * lane + q] : 0.0f;
+      acc = dc_guess<false> (tk, m, z0, B, lane, zt, v);
+    }
+    const u64 bad = __ballot (acc != 0);
+    const int s_prev = -1;
+    if (!bad && whole) {
+      float4 *dst = reinterpret_cast<float4 *> (zo + base + kDcPer * lane);
+#pragma unroll
+      for (int g = 0; g < kDcPer / 4; g++) { float4 o; o.x = zt[4 * g]; o.y = zt[4 * g + 1]; o.z = zt[4 * g + 2]; o.w = zt[4 * g + 3]; dst[g] = o; }
+      z0 = bcast_lane (zt[kDcPer - 1], 63);
+      base += kDcRound;
+      backoff = 0;
+      continue;
+    }
+    int adv = m;
+    if (bad) {
+      const int j = __builtin_ctzll (bad);
+      int f = kDcPer;
+#pragma unroll
+      for (int q = kDcPer - 1; q >= 0; q--)
+        if (kDcPer * lane + q < m && kDcPer * lane + q > s_prev && __float_as_uint (v[q]) != __float_as_uint (zt[q])) f = q;
+      const int fj = __builtin_amdgcn_readlane (f, j);
+      adv = kDcPer * j + fj + 1;                                 // that lane's real step is exact: keep it too
+#pragma unroll
+      for (int q = 0; q < kDcPer; q++) if (lane == j && q == fj) zt[q] = v[q];
+    }
+    float last = 0.0f;
+#pragma unroll
+    for (int q = 0; q < kDcPer; q++) {
+      const int i = kDcPer * lane + q;
+      if (i < adv) zo[base + i] = zt[q];
+      if (i == adv - 1) last = zt[q];
+    }
+    z0 = bcast_lane (last, (adv - 1) / kDcPer);
+    base += adv;
+    // a guess that got nowhere: step plainly for a while, twice as long every time it happens again (z1 sitting on a
+    // boundary of the product's rounding fails guess after guess)
+    if (adv < kDcRound / 4 && m == kDcRound) { backoff = backoff ? (backoff < 32 ? 2 * backoff : 32) : 1; plain = backoff; }
+    else if (adv >= kDcRound / 2) backoff = 0;
+  }
+  return z0;
+}
+
 template <int CONV>
-__global__ __launch_bounds__ (64)
+__global__ __launch_bounds__ (256)
 void dc_chain_kernel (const DcParams p)
 {
   __shared__ __attribute__ ((aligned (16))) float s_t[2][kDcBatch];   // f * DC_A per channel
-  __shared__ __attribute__ ((aligned (16))) float s_z[4][kDcBatch];   // z1 after every sample, per chain lane
+  __shared__ __attribute__ ((aligned (16))) float s_z[4][kDcBatch];   // z1 behind every sample, per chain
   __shared__ float s_uc8[256];
-  const int lane = threadIdx.x;
-  if (CONV == kConvUc8Generic) {
-    for (int b = lane; b < 256; b += 64) s_uc8[b] = float ((double (b) - 127.5) / 127.5);   // ref: src/convert.c:131
-    __builtin_amdgcn_s_waitcnt (0xc07f);
-    __builtin_amdgcn_wave_barrier ();
-  }
+  __shared__ float s_state[4];                                        // I-lo, I-hi, Q-lo, Q-hi behind the last batch
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const DcChunk d = p.desc[blockIdx.x];
+  if (CONV == kConvUc8Generic) s_uc8[tid] = float ((double (tid) - 127.5) / 127.5);       // ref: src/convert.c:131
+  if (tid == 0) { s_state[0] = d.zIlo; s_state[1] = d.zIhi; s_state[2] = d.zQlo; s_state[3] = d.zQhi; }
+  __syncthreads ();
   const long long c0 = (long long) d.chunk * (long long) p.chunk_len;
   const long long c1 = min (c0 + (long long) p.chunk_len, (long long) p.n);
-  float z = lane == 0 ? d.zIlo : lane == 1 ? d.zIhi : lane == 2 ? d.zQlo : d.zQhi;
+  float z = wv == 0 ? d.zIlo : wv == 1 ? d.zIhi : wv == 2 ? d.zQlo : d.zQhi;
   const float A = p.A, B = p.B;
-  const int ch = (lane >> 1) & 1;
+  uint32_t n_guess = 0, n_plain = 0;
+  int backoff = 0;
+  long long tm_chain = 0, tm_bar = 0, tm_total = clock64 ();
 
-  DcRaw<CONV> raw;
-  dc_load4<CONV> (p.iq, d.start + 4 * lane, c1, raw);
+  constexpr int NG = kDcBatch / 1024;                                // groups of 1024 samples: four per thread each
+  DcRaw<CONV> raw[NG];
+#pragma unroll
+  for (int g = 0; g < NG; g++) dc_load4<CONV> (p.iq, d.start + 1024 * g + 4 * tid, c1, raw[g]);
   for (long long b = d.start; b < c1; b += kDcBatch) {
-    float fI[4], fQ[4];
-    dc_to_float<CONV> (raw, s_uc8, fI, fQ);
-    if (b + kDcBatch < c1) dc_load4<CONV> (p.iq, b + kDcBatch + 4 * lane, c1, raw);     // next batch, in flight behind the chain
-    {
+    float fI[NG][4], fQ[NG][4];
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+      dc_to_float<CONV> (raw[g], s_uc8, fI[g], fQ[g]);
+      if (b + kDcBatch < c1) dc_load4<CONV> (p.iq, b + kDcBatch + 1024 * g + 4 * tid, c1, raw[g]);   // next batch, in flight behind the chains
       float4 tI, tQ;
-      tI.x = __fmul_rn (fI[0], A); tI.y = __fmul_rn (fI[1], A); tI.z = __fmul_rn (fI[2], A); tI.w = __fmul_rn (fI[3], A);
-      tQ.x = __fmul_rn (fQ[0], A); tQ.y = __fmul_rn (fQ[1], A); tQ.z = __fmul_rn (fQ[2], A); tQ.w = __fmul_rn (fQ[3], A);
-      *reinterpret_cast<float4 *> (&s_t[0][4 * lane]) = tI;
-      *reinterpret_cast<float4 *> (&s_t[1][4 * lane]) = tQ;
+      tI.x = __fmul_rn (fI[g][0], A); tI.y = __fmul_rn (fI[g][1], A); tI.z = __fmul_rn (fI[g][2], A); tI.w = __fmul_rn (fI[g][3], A);
+      tQ.x = __fmul_rn (fQ[g][0], A); tQ.y = __fmul_rn (fQ[g][1], A); tQ.z = __fmul_rn (fQ[g][2], A); tQ.w = __fmul_rn (fQ[g][3], A);
+      *reinterpret_cast<float4 *> (&s_t[0][1024 * g + 4 * tid]) = tI;
+      *reinterpret_cast<float4 *> (&s_t[1][1024 * g + 4 * tid]) = tQ;
     }
-    __builtin_amdgcn_s_waitcnt (0xc07f);
-    __builtin_amdgcn_wave_barrier ();
+    // the states the chains hold in front of this batch
+    const float sIlo = s_state[0], sIhi = s_state[1], sQlo = s_state[2], sQhi = s_state[3];
+    long long tb = clock64 ();
+    __syncthreads ();
+    tm_bar += clock64 () - tb;
     const bool region = b >= c0;
-    if (b == c0) {                      // first sample of the chunk: has the bracket closed?
-      const float other = __shfl_xor (z, 1, 64);
-      const bool open = lane < 4 && !(z == other);
-      const u64 m = __ballot (open);
-      if (lane < 4) p.z_start[4 * size_t (d.chunk) + lane] = z;
-      if (lane == 0) p.unmerged[d.chunk] = m ? 1u : 0u;
+    if (b == c0 && tid == 0) {            // first sample of the chunk: have the brackets closed?
+      float *zs = p.z_start + 4 * size_t (d.chunk);
+      zs[0] = sIlo; zs[1] = sIhi; zs[2] = sQlo; zs[3] = sQhi;
+      p.unmerged[d.chunk] = (sIlo == sIhi && sQlo == sQhi) ? 0u : 1u;
     }
     const int cnt = int (min ((long long) kDcBatch, c1 - b));
-    if (lane < 4) {
-      const float *t = s_t[ch];
-      float *zo = s_z[lane];
-      if (cnt == kDcBatch) {
-        // 32 samples at a time: their eight LDS reads are in flight while the 32 before them are stepped
-        constexpr int G = 8;                        // float4 per group
-        float4 cur[G], nxt[G];
-#pragma unroll
-        for (int k = 0; k < G; k++) cur[k] = *reinterpret_cast<const float4 *> (t + 4 * k);
-#pragma unroll
-        for (int g = 0; g < kDcBatch / (4 * G); g++) {
-          if (g + 1 < kDcBatch / (4 * G)) {
-#pragma unroll
-            for (int k = 0; k < G; k++) nxt[k] = *reinterpret_cast<const float4 *> (t + 4 * G * (g + 1) + 4 * k);
-          }
-#pragma unroll
-          for (int k = 0; k < G; k++) {
-            float4 o;
-            z = __fadd_rn (cur[k].x, __fmul_rn (z, B)); o.x = z;       // ref: src/convert.c:137-140 (one rounding per operation)
-            z = __fadd_rn (cur[k].y, __fmul_rn (z, B)); o.y = z;
-            z = __fadd_rn (cur[k].z, __fmul_rn (z, B)); o.z = z;
-            z = __fadd_rn (cur[k].w, __fmul_rn (z, B)); o.w = z;
-            *reinterpret_cast<float4 *> (zo + 4 * G * g + 4 * k) = o;
-          }
-#pragma unroll
-          for (int k = 0; k < G; k++) cur[k] = nxt[k];
-        }
-      } else {
-        for (int i = 0; i < cnt; i++) { z = __fadd_rn (t[i], __fmul_rn (z, B)); zo[i] = z; }
+    const bool closed = (wv & 1) && (wv == 1 ? sIlo == sIhi : sQlo == sQhi);     // a hi chain that has met its lo chain
+    if (!closed) {
+      const long long tc = clock64 ();
+      z = dc_chain_batch (s_t[wv >> 1], s_z[wv], cnt, z, B, lane, n_guess, n_plain, backoff);
+      if (lane == 0) {
+        s_state[wv] = z;
+        if (!(wv & 1) && (wv == 0 ? sIlo == sIhi : sQlo == sQhi)) s_state[wv + 1] = z;   // the closed hi chain follows
       }
+      tm_chain += clock64 () - tc;
     }
-    __builtin_amdgcn_s_waitcnt (0xc07f);
-    __builtin_amdgcn_wave_barrier ();
+    tb = clock64 ();
+    __syncthreads ();
+    tm_bar += clock64 () - tb;
+    if (closed) z = s_state[wv];
     if (region) {
-      const float4 zI = *reinterpret_cast<const float4 *> (&s_z[0][4 * lane]);
-      const float4 zQ = *reinterpret_cast<const float4 *> (&s_z[2][4 * lane]);
-      const float zi[4] = { zI.x, zI.y, zI.z, zI.w }, zq[4] = { zQ.x, zQ.y, zQ.z, zQ.w };
-      uint32_t m[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++)                                  // ref: src/convert.c:139-147
-        m[k] = mag_from_float (__fsub_rn (fI[k], zi[k]), __fsub_rn (fQ[k], zq[k]), nullptr);
-      uint16_t *dst = p.mag + b + 4 * lane;
-      if (4 * lane + 4 <= cnt) {
-        uint32_t *d32 = reinterpret_cast<uint32_t *> (dst);        // p.mag is 4-byte aligned, b and 4 * lane are even
-        d32[0] = m[0] | (m[1] << 16); d32[1] = m[2] | (m[3] << 16);
-      } else {
+      for (int g = 0; g < NG; g++) {
+        const int o = 1024 * g + 4 * tid;
+        if (o >= cnt) break;
+        const float4 zI = *reinterpret_cast<const float4 *> (&s_z[0][o]);
+        const float4 zQ = *reinterpret_cast<const float4 *> (&s_z[2][o]);
+        const float zi[4] = { zI.x, zI.y, zI.z, zI.w }, zq[4] = { zQ.x, zQ.y, zQ.z, zQ.w };
+        uint32_t m[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) if (4 * lane + k < cnt) dst[k] = uint16_t (m[k]);
+        for (int k = 0; k < 4; k++)                                // ref: src/convert.c:139-147
+          m[k] = mag_from_float (__fsub_rn (fI[g][k], zi[k]), __fsub_rn (fQ[g][k], zq[k]), nullptr);
+        uint16_t *dst = p.mag + b + o;
+        if (o + 4 <= cnt) {
+          uint32_t *d32 = reinterpret_cast<uint32_t *> (dst);      // p.mag is 4-byte aligned, b and o are even
+          d32[0] = m[0] | (m[1] << 16); d32[1] = m[2] | (m[3] << 16);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; k++) if (o + k < cnt) dst[k] = uint16_t (m[k]);
+        }
       }
-      __builtin_amdgcn_s_waitcnt (0xc07f);
-      __builtin_amdgcn_wave_barrier ();                            // s_z is rewritten by the next batch's chain
     }
   }
-  const float zq_end = __shfl (z, 2, 64);
-  if (lane == 0) { p.z_end[2 * size_t (d.chunk)] = z; p.z_end[2 * size_t (d.chunk) + 1] = zq_end; }
+  __syncthreads ();
+  if (tid == 0) { p.z_end[2 * size_t (d.chunk)] = s_state[0]; p.z_end[2 * size_t (d.chunk) + 1] = s_state[2]; }
+  if (lane == 0 && p.ticks) { unsigned long long *o = p.ticks + 16 * size_t (d.chunk) + 5 + 2 * wv; o[0] = n_guess; o[1] = n_plain; }
+  if (lane == 0 && p.rounds) { atomicAdd (&p.rounds[0], (unsigned long long) n_guess); atomicAdd (&p.rounds[1], (unsigned long long) n_plain);
+    if (wv == 0) { atomicAdd (&p.rounds[2], (unsigned long long) tm_chain); atomicAdd (&p.rounds[3], (unsigned long long) tm_bar); atomicAdd (&p.rounds[4], (unsigned long long) (clock64 () - tm_total)); atomicMax (&p.rounds[5], (unsigned long long) (clock64 () - tm_total)); if (p.ticks) { unsigned long long *o = p.ticks + 16 * size_t (d.chunk); o[0] = (unsigned long long) (clock64 () - tm_total); o[1] = n_guess; o[2] = n_plain; o[3] = (unsigned long long) tm_chain; o[4] = (unsigned long long) tm_bar; } } }
 }
 
 hipError_t launch_dc_chain (int conv, const DcParams &p, uint32_t ndesc, hipStream_t stream)
 {
   if (ndesc == 0) return hipSuccess;
-  const dim3 grid (ndesc), block (64);
+  const dim3 grid (ndesc), block (256);
   switch (conv) {
     case kConvUc8Generic:     hipLaunchKernelGGL (dc_chain_kernel<kConvUc8Generic>, grid, block, 0, stream, p); break;
     case kConvSc16Generic:    hipLaunchKernelGGL (dc_chain_kernel<kConvSc16Generic>, grid, block, 0, stream, p); break;

@@ -251,6 +251,9 @@ typedef struct modes_dc_info {
   uint64_t chunk_samples, warm_samples;
   float    chain_ms;         /* duration of the chain kernel (HIP events on the launch stream) */
   uint32_t reserved;
+  uint64_t guess_rounds;     /* 256-sample guesses tried by all chains of the first pass          */
+  uint64_t plain_rounds;     /* 64-sample runs stepped one by one after a guess got nowhere       */
+  uint64_t chain_steps;      /* filter steps of all chains of the first pass (warm-up included)  */
 } modes_dc_info;
 int  modes_engine_get_dc_info (const modes_engine *e, modes_dc_info *out);
 /* The magnitudes of the last filter_dc run in device memory: `overlap` entries in front of the shard's first sample,
