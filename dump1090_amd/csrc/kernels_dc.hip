@@ -16,12 +16,9 @@
 // A chunk whose bracket has not closed at its first sample is reported (`unmerged`) and re-run by the
 // host from the exact end state of the chunk before it.
 //
-// A chain is a latency problem: two dependent operations per sample.  A wave therefore steps 1024 samples at once on
-// a GUESS and keeps what it can prove.  While z1 stays inside one binade and RN (z*B) keeps the same distance r to z,
-// every step adds an integer number of ulps:  z[k] = z0 + sum_{i<=k} (RN_ulp (t[i]) - r)  -- a prefix sum over the
-// lanes.  Lane k then performs the REAL step from the guessed z[k-1] and compares bit for bit with the guessed z[k]:
-// up to the first lane that disagrees the guesses are the reference's values by induction, and that lane's real
-// step is the next exact value.  Where guesses keep failing (z1 near zero) the wave falls back to plain steps.
+// A chain is a latency problem: two dependent operations per sample.  A wave therefore steps 1024 samples at once,
+// sixteen per lane, from guessed lane starts and keeps what it can prove (see dc_round below); where the guesses
+// keep failing (z1 next to zero, or sitting on a boundary of the product's rounding) it steps plainly for a while.
 //
 // "ref:" citations are relative to the reference's root.
 #include <hip/hip_runtime.h>
@@ -81,6 +78,11 @@ __device__ __forceinline__ float wave_incl_scan_f (float v)
   return v;
 }
 
+// LDS index of sample i of a batch.  (Padding 16 bytes behind every 64 floats, to spread the lanes' 64-byte-stride
+// groups over the banks, was measured and bought nothing: the rounds are bound by dependent latency, not by LDS.)
+__device__ __forceinline__ int dcp (int i) { return i; }
+constexpr int kDcBatchLds = kDcBatch;
+
 constexpr int kDcPer = 16;                      // consecutive samples per lane in one guess
 constexpr int kDcRound = 64 * kDcPer;           // samples per guess
 
@@ -89,38 +91,80 @@ __device__ __forceinline__ float bcast_lane (float x, int l)
   return __uint_as_float (uint32_t (__builtin_amdgcn_readlane (int (__float_as_uint (x)), l)));
 }
 
-// The guess for kDcRound samples, kDcPer consecutive ones per lane: tk[q] = t of sample kDcPer * lane + q (only the
-// first m samples exist).  zt[q] = guessed z1 behind that sample, v[q] = the real step from the guessed predecessor
-// (ref: src/convert.c:137-140).  Returns the OR of v ^ zt over the lane's existing samples: 0 = every guess holds.
-template <bool WHOLE>
-__device__ __forceinline__ uint32_t dc_guess (const float *tk, int m, float z0, float B, int lane, float *zt, float *v)
+// ---- one round of a chain: kDcRound samples, kDcPer consecutive ones per lane ----------------------------------
+// Every lane steps its own samples with the REAL operations (ref: src/convert.c:137-140), so what happens inside a
+// lane -- ties of the rounding included -- is the reference's arithmetic; only the value a lane STARTS from is
+// guessed.  While z1 stays inside one binade and RN (z * B) keeps its distance to z, moving the start by a whole
+// number of ulps moves every later value by the same amount, except that a tie of RN (t + z * B) falls the other
+// way when the start moves by an odd number.  So each lane first steps its samples from z0 and from z0 + 1 ulp:
+// that yields its increment and the parity of its increment for an even and for an odd start offset, i.e. a map
+// (offset parity in) -> (offset parity out, increment).  The maps compose associatively; a scan over the lanes gives
+// every lane its start offset, the lane steps again from there, and the round is accepted up to the first lane
+// whose start differs, bit for bit, from the value the lane below ended on (exact by induction from z0).
+struct DcMap { uint32_t n; float d0, d1; };        // n bit p: the parity flips for an input parity p; d_p: increment
+
+__device__ __forceinline__ DcMap dc_compose (const DcMap y, const DcMap x)      // y first, then x
 {
-  const float r = __fsub_rn (z0, __fmul_rn (z0, B));             // what the product takes off z0
-  const float c1 = __fadd_rn (z0, r);
-  float pf[kDcPer];                                              // inclusive sums of the lane's own increments, in ulps of z0
+  DcMap o;
+  const bool f0 = y.n & 1u, f1 = y.n & 2u;         // parity after y for inputs 0, 1 is 0 ^ f0, 1 ^ f1
+  const uint32_t x0 = f0 ? (x.n >> 1) & 1u : x.n & 1u;          // x's flip at parity (0 ^ f0)
+  const uint32_t x1 = f1 ? x.n & 1u : (x.n >> 1) & 1u;          // x's flip at parity (1 ^ f1)
+  o.n = ((y.n & 1u) ^ x0) | ((((y.n >> 1) & 1u) ^ x1) << 1);
+  o.d0 = __fadd_rn (y.d0, f0 ? x.d1 : x.d0);
+  o.d1 = __fadd_rn (y.d1, f1 ? x.d0 : x.d1);
+  return o;
+}
+
+template <int CTRL, int MASK, bool BOUND>
+__device__ __forceinline__ DcMap dc_map_dpp (const DcMap x)
+{
+  DcMap y;
+  y.n = dpp_mov<CTRL, MASK, BOUND> (x.n);
+  y.d0 = __uint_as_float (dpp_mov<CTRL, MASK, BOUND> (__float_as_uint (x.d0)));
+  y.d1 = __uint_as_float (dpp_mov<CTRL, MASK, BOUND> (__float_as_uint (x.d1)));
+  return y;
+}
+
+// inclusive scan of the lanes' maps (all-zero = the identity, which is what DPP fills in)
+__device__ __forceinline__ DcMap dc_map_scan (DcMap x)
+{
+  x = dc_compose (dc_map_dpp<0x111, 0xF, true> (x), x);
+  x = dc_compose (dc_map_dpp<0x112, 0xF, true> (x), x);
+  x = dc_compose (dc_map_dpp<0x114, 0xF, true> (x), x);
+  x = dc_compose (dc_map_dpp<0x118, 0xF, true> (x), x);
+  x = dc_compose (dc_map_dpp<0x142, 0xA, false> (x), x);
+  x = dc_compose (dc_map_dpp<0x143, 0xC, false> (x), x);
+  return x;
+}
+
+// tk[q] = t of sample kDcPer * lane + q.  On return zt[q] = z1 behind that sample as stepped from the lane's start;
+// the result is the number of leading lanes whose values are proven (64 = the whole round).
+__device__ __forceinline__ int dc_round (const float *tk, float z0, float B, int lane, float *zt)
+{
+  const uint32_t zb = __float_as_uint (z0);
+  const float z1u = __uint_as_float (zb + 1u);                   // one ulp further from zero: the odd start
+  float za = z0, zo = z1u;
 #pragma unroll
   for (int q = 0; q < kDcPer; q++) {
-    const float dq = __fsub_rn (__fadd_rn (z0, tk[q]), c1);      // (t rounded to z0's grid) - r
-    pf[q] = q ? __fadd_rn (pf[q - 1], dq) : dq;
+    za = __fadd_rn (tk[q], __fmul_rn (za, B));
+    zo = __fadd_rn (tk[q], __fmul_rn (zo, B));
   }
-  const float incl = wave_incl_scan_f (pf[kDcPer - 1]);
-  float ex = __uint_as_float (dpp_mov<0x138, 0xF, true> (__float_as_uint (incl)));        // wave_shr:1: sum of the lanes below
-  if (lane == 0) ex = 0.0f;
-  const float zp0 = __fadd_rn (z0, ex);
+  DcMap mp;
+  mp.d0 = __fsub_rn (za, z0);
+  mp.d1 = __fsub_rn (zo, z1u);
+  mp.n = ((__float_as_uint (za) ^ zb) & 1u) | (((__float_as_uint (zo) ^ zb ^ 1u) & 1u) << 1);
+  const DcMap in = dc_map_scan (mp);
+  DcMap ex = dc_map_dpp<0x138, 0xF, true> (in);                  // wave_shr:1: the lanes below
+  if (lane == 0) { ex.n = 0; ex.d0 = 0.0f; ex.d1 = 0.0f; }
+  // the chain enters the round at offset 0 (even): start of this lane = z0 + increment of the lanes below
+  const float start = __fadd_rn (z0, ex.d0);
+  float z = start;
 #pragma unroll
-  for (int q = 0; q < kDcPer; q++) zt[q] = __fadd_rn (zp0, pf[q]);
-  // the predecessor of the lane's first sample is the guess the lane below makes for its last one, bit for bit
-  // (not zp0: the two only agree while every sum above is exact) -- the induction over the samples rests on it
-  float zprev = __uint_as_float (dpp_mov<0x138, 0xF, true> (__float_as_uint (zt[kDcPer - 1])));
-  if (lane == 0) zprev = z0;
-  uint32_t acc = 0;
-#pragma unroll
-  for (int q = 0; q < kDcPer; q++) {
-    v[q] = __fadd_rn (tk[q], __fmul_rn (q ? zt[q - 1] : zprev, B));
-    const uint32_t x = __float_as_uint (v[q]) ^ __float_as_uint (zt[q]);
-    acc |= (WHOLE || kDcPer * lane + q < m) ? x : 0u;
-  }
-  return acc;
+  for (int q = 0; q < kDcPer; q++) { z = __fadd_rn (tk[q], __fmul_rn (z, B)); zt[q] = z; }
+  float below = __uint_as_float (dpp_mov<0x138, 0xF, true> (__float_as_uint (z)));
+  if (lane == 0) below = z0;
+  const u64 bad = __ballot (__float_as_uint (below) != __float_as_uint (start));
+  return bad ? __builtin_ctzll (bad) : 64;
 }
 
 // One chain over t[0 .. cnt): returns z1 behind the last sample, zo[i] = z1 behind sample i.  z0 is uniform.
@@ -130,82 +174,50 @@ __device__ __forceinline__ float dc_chain_batch (const float *t, float *zo, int 
   int base = 0, plain = 0;
   while (base < cnt) {
     const int rem = cnt - base;
-    if (plain) {                                  // plain steps (ref: src/convert.c:137-140), then guess again
-      int m = 64 * plain;
+    if (plain || rem < kDcRound || (base & 3)) {  // plain steps (ref: src/convert.c:137-140), then guess again
+      int m = plain ? 64 * plain : rem < kDcRound ? rem : 4 - (base & 3);
       if (m > rem) m = rem;
+      // every lane steps the same chain: a dependent VALU operation of a wave with one active lane takes four times
+      // as long as one with all lanes active (tools/ubench/dep_latency2.hip: 35 against 8.6 cycles per step)
       float z = z0;
-      if (lane == 0) {
-        int i = 0;
-        for (; i < m && ((base + i) & 3); i++) { z = __fadd_rn (t[base + i], __fmul_rn (z, B)); zo[base + i] = z; }
-        float4 nx = i + 4 <= m ? *reinterpret_cast<const float4 *> (t + base + i) : make_float4 (0.0f, 0.0f, 0.0f, 0.0f);
-        for (; i + 4 <= m; i += 4) {
-          const float4 x = nx;
-          if (i + 8 <= m) nx = *reinterpret_cast<const float4 *> (t + base + i + 4);      // in flight behind the four steps
-          float4 o;
-          z = __fadd_rn (x.x, __fmul_rn (z, B)); o.x = z;
-          z = __fadd_rn (x.y, __fmul_rn (z, B)); o.y = z;
-          z = __fadd_rn (x.z, __fmul_rn (z, B)); o.z = z;
-          z = __fadd_rn (x.w, __fmul_rn (z, B)); o.w = z;
-          *reinterpret_cast<float4 *> (zo + base + i) = o;
-        }
-        for (; i < m; i++) { z = __fadd_rn (t[base + i], __fmul_rn (z, B)); zo[base + i] = z; }
+      const bool st = lane == 0;
+      int i = 0;
+      for (; i < m && ((base + i) & 3); i++) { z = __fadd_rn (t[dcp (base + i)], __fmul_rn (z, B)); if (st) zo[dcp (base + i)] = z; }
+      float4 nx = i + 4 <= m ? *reinterpret_cast<const float4 *> (t + dcp (base + i)) : make_float4 (0.0f, 0.0f, 0.0f, 0.0f);
+      for (; i + 4 <= m; i += 4) {
+        const float4 x = nx;
+        if (i + 8 <= m) nx = *reinterpret_cast<const float4 *> (t + dcp (base + i + 4));  // in flight behind the four steps
+        float4 o;
+        z = __fadd_rn (x.x, __fmul_rn (z, B)); o.x = z;
+        z = __fadd_rn (x.y, __fmul_rn (z, B)); o.y = z;
+        z = __fadd_rn (x.z, __fmul_rn (z, B)); o.z = z;
+        z = __fadd_rn (x.w, __fmul_rn (z, B)); o.w = z;
+        if (st) *reinterpret_cast<float4 *> (zo + dcp (base + i)) = o;
       }
-      z0 = __uint_as_float (uint32_t (__builtin_amdgcn_readfirstlane (int (__float_as_uint (z)))));
-      base += m; n_plain += uint32_t (plain); plain = 0;
+      for (; i < m; i++) { z = __fadd_rn (t[dcp (base + i)], __fmul_rn (z, B)); if (st) zo[dcp (base + i)] = z; }
+      z0 = z;
+      base += m; n_plain += uint32_t ((m + 63) / 64); plain = 0;
       continue;
     }
     n_guess++;
-    float tk[kDcPer], zt[kDcPer], v[kDcPer];
-    const bool whole = rem >= kDcRound && !(base & 3);
-    int m = rem < kDcRound ? rem : kDcRound;
-    if ((base & 3) && m > kDcRound - (base & 3)) m = kDcRound - (base & 3);       // end on the 16-byte grid again
-    uint32_t acc;
-    if (whole) {                                  // the common round: aligned 16-byte LDS accesses
-      const float4 *src = reinterpret_cast<const float4 *> (t + base + kDcPer * lane);
+    float tk[kDcPer], zt[kDcPer];
+    {
+      const float4 *src = reinterpret_cast<const float4 *> (t + dcp (base + kDcPer * lane));
 #pragma unroll
       for (int g = 0; g < kDcPer / 4; g++) { const float4 x = src[g]; tk[4 * g] = x.x; tk[4 * g + 1] = x.y; tk[4 * g + 2] = x.z; tk[4 * g + 3] = x.w; }
-      acc = dc_guess<true> (tk, m, z0, B, lane, zt, v);
-    } else {                                      // the ragged end of the batch, or a start off the 16-byte grid
-#pragma unroll
-      for (int q = 0; q < kDcPer; q++) tk[q] = kDcPer * lane + q < m ? t[base + kDcPer * lane + q] : 0.0f;
-      acc = dc_guess<false> (tk, m, z0, B, lane, zt, v);
     }
-    const u64 bad = __ballot (acc != 0);
-    const int s_prev = -1;
-    if (!bad && whole) {
-      float4 *dst = reinterpret_cast<float4 *> (zo + base + kDcPer * lane);
+    const int good = dc_round (tk, z0, B, lane, zt);             // >= 1: lane 0 starts from z0 itself
+    if (lane < good) {
+      float4 *dst = reinterpret_cast<float4 *> (zo + dcp (base + kDcPer * lane));
 #pragma unroll
       for (int g = 0; g < kDcPer / 4; g++) { float4 o; o.x = zt[4 * g]; o.y = zt[4 * g + 1]; o.z = zt[4 * g + 2]; o.w = zt[4 * g + 3]; dst[g] = o; }
-      z0 = bcast_lane (zt[kDcPer - 1], 63);
-      base += kDcRound;
-      backoff = 0;
-      continue;
     }
-    int adv = m;
-    if (bad) {
-      const int j = __builtin_ctzll (bad);
-      int f = kDcPer;
-#pragma unroll
-      for (int q = kDcPer - 1; q >= 0; q--)
-        if (kDcPer * lane + q < m && kDcPer * lane + q > s_prev && __float_as_uint (v[q]) != __float_as_uint (zt[q])) f = q;
-      const int fj = __builtin_amdgcn_readlane (f, j);
-      adv = kDcPer * j + fj + 1;                                 // that lane's real step is exact: keep it too
-#pragma unroll
-      for (int q = 0; q < kDcPer; q++) if (lane == j && q == fj) zt[q] = v[q];
-    }
-    float last = 0.0f;
-#pragma unroll
-    for (int q = 0; q < kDcPer; q++) {
-      const int i = kDcPer * lane + q;
-      if (i < adv) zo[base + i] = zt[q];
-      if (i == adv - 1) last = zt[q];
-    }
-    z0 = bcast_lane (last, (adv - 1) / kDcPer);
-    base += adv;
-    // a guess that got nowhere: step plainly for a while, twice as long every time it happens again (z1 sitting on a
-    // boundary of the product's rounding fails guess after guess)
-    if (adv < kDcRound / 4 && m == kDcRound) { backoff = backoff ? (backoff < 32 ? 2 * backoff : 32) : 1; plain = backoff; }
-    else if (adv >= kDcRound / 2) backoff = 0;
+    z0 = bcast_lane (zt[kDcPer - 1], good - 1);
+    base += kDcPer * good;
+    // a round that got nowhere: step plainly for a while, twice as long every time it happens again (z1 sitting on a
+    // boundary of the product's rounding, or next to zero, fails round after round)
+    if (good < 16) { backoff = backoff ? (backoff < 32 ? 2 * backoff : 32) : 1; plain = backoff; }
+    else if (good >= 32) backoff = 0;
   }
   return z0;
 }
@@ -214,8 +226,8 @@ template <int CONV>
 __global__ __launch_bounds__ (256)
 void dc_chain_kernel (const DcParams p)
 {
-  __shared__ __attribute__ ((aligned (16))) float s_t[2][kDcBatch];   // f * DC_A per channel
-  __shared__ __attribute__ ((aligned (16))) float s_z[4][kDcBatch];   // z1 behind every sample, per chain
+  __shared__ __attribute__ ((aligned (16))) float s_t[2][kDcBatchLds];   // f * DC_A per channel
+  __shared__ __attribute__ ((aligned (16))) float s_z[4][kDcBatchLds];   // z1 behind every sample, per chain
   __shared__ float s_uc8[256];
   __shared__ float s_state[4];                                        // I-lo, I-hi, Q-lo, Q-hi behind the last batch
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -244,8 +256,8 @@ void dc_chain_kernel (const DcParams p)
       float4 tI, tQ;
       tI.x = __fmul_rn (fI[g][0], A); tI.y = __fmul_rn (fI[g][1], A); tI.z = __fmul_rn (fI[g][2], A); tI.w = __fmul_rn (fI[g][3], A);
       tQ.x = __fmul_rn (fQ[g][0], A); tQ.y = __fmul_rn (fQ[g][1], A); tQ.z = __fmul_rn (fQ[g][2], A); tQ.w = __fmul_rn (fQ[g][3], A);
-      *reinterpret_cast<float4 *> (&s_t[0][1024 * g + 4 * tid]) = tI;
-      *reinterpret_cast<float4 *> (&s_t[1][1024 * g + 4 * tid]) = tQ;
+      *reinterpret_cast<float4 *> (&s_t[0][dcp (1024 * g + 4 * tid)]) = tI;
+      *reinterpret_cast<float4 *> (&s_t[1][dcp (1024 * g + 4 * tid)]) = tQ;
     }
     // the states the chains hold in front of this batch
     const float sIlo = s_state[0], sIhi = s_state[1], sQlo = s_state[2], sQhi = s_state[3];
@@ -278,8 +290,8 @@ void dc_chain_kernel (const DcParams p)
       for (int g = 0; g < NG; g++) {
         const int o = 1024 * g + 4 * tid;
         if (o >= cnt) break;
-        const float4 zI = *reinterpret_cast<const float4 *> (&s_z[0][o]);
-        const float4 zQ = *reinterpret_cast<const float4 *> (&s_z[2][o]);
+        const float4 zI = *reinterpret_cast<const float4 *> (&s_z[0][dcp (o)]);
+        const float4 zQ = *reinterpret_cast<const float4 *> (&s_z[2][dcp (o)]);
         const float zi[4] = { zI.x, zI.y, zI.z, zI.w }, zq[4] = { zQ.x, zQ.y, zQ.z, zQ.w };
         uint32_t m[4];
 #pragma unroll
