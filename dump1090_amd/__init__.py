@@ -35,7 +35,7 @@ class EngineConfig(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
                 ("valid_preamble", "demodulated", "out_of_phase", "demod_modeac", "CRC_good", "CRC_bad", "CRC_fixed",
-                 "CRC_single_bit_fix", "CRC_two_bits_fix", "demod_rejected_unknown", "candidates", "replay_rounds")]
+                 "CRC_single_bit_fix", "CRC_two_bits_fix", "demod_rejected_unknown", "candidates", "replay_rounds", "scan_retries")]
 
     def asdict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

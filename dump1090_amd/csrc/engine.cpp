@@ -499,6 +499,7 @@ int modes_engine_create (const modes_engine_config *cfg, modes_engine **out)
   e->block_samples = kAsyncBufSize / bytes_per_sample (cfg->input_format);
   e->mode = cfg->sample_rate == 2000000 ? 2000 : cfg->sample_rate == 8000000 ? 8000 : 2400;
   e->cap = e->mode == 2000 ? uint32_t (cfg->phase_enhance ? kCap2000PE : kCap2000) : cfg->phase_enhance ? 128 : 32;
+  if (const char *ev = getenv ("MODES_STRIP_SLOTS")) if (atoi (ev) > 0) e->cap = uint32_t (atoi (ev));   // test hook: start small, grow on demand
   memset (&e->stats, 0, sizeof e->stats);
   memset (&e->dc_info, 0, sizeof e->dc_info);
   if (cfg->filter_dc) {                       // ref: src/convert.c:349-354
@@ -557,6 +558,8 @@ int modes_engine_get_icao (modes_engine *e, uint32_t *slots)
   return MODES_OK;
 }
 
+static int scan_and_decode (modes_engine *e, ScanParams &sp, uint64_t first_sample, hipStream_t stream);
+
 static int run_device_inner (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t first_sample,
                              const uint16_t *d_halo, void *stream_v)
 {
@@ -573,7 +576,29 @@ static int run_device_inner (modes_engine *e, const void *d_iq, size_t nbytes, u
   if (rc != MODES_OK) return rc;
   if (e->cfg.filter_dc && (rc = prepare_dc (e, d_iq, nbytes, d_halo, stream, &sp)) != MODES_OK) return rc;
   if (sp.nstrips == 0) return MODES_OK;
+  // A strip that holds more candidates than its slots is reported, never cut short: scan again with four times the
+  // slots (up to one per position and retry kind) until everything fits.
+  const uint32_t cap_max = e->mode == 2000 ? 3u * kStrip : uint32_t (kStrip);
+  std::vector<uint32_t> cache_in (e->cache.raw (), e->cache.raw () + kIcaoSlots);      // an overflowed attempt may have touched it
+  for (;;) {
+    rc = scan_and_decode (e, sp, first_sample, stream);
+    if (rc != MODES_E_OVERFLOW || e->cap >= cap_max) return rc;
+    e->cap = e->cap * 4 < cap_max ? e->cap * 4 : cap_max;
+    e->stats.scan_retries++;
+    const uint64_t retries = e->stats.scan_retries;
+    if ((rc = e->records.reserve (size_t (sp.nstrips) * e->cap)) != MODES_OK) return rc;
+    sp.records = e->records.p; sp.cap = e->cap;
+    e->messages.clear ();
+    e->in_pinned = false; e->pin_n = 0;
+    memset (&e->stats, 0, sizeof e->stats);
+    e->stats.scan_retries = retries;
+    memcpy (e->cache.raw (), cache_in.data (), kIcaoSlots * sizeof (uint32_t));
+  }
+}
 
+static int scan_and_decode (modes_engine *e, ScanParams &sp, uint64_t first_sample, hipStream_t stream)
+{
+  int rc;
   HIP_TRY (hipEventRecord (e->ev[0], stream));
   HIP_TRY (e->mode == 2000 ? launch_scan2000 (sp, stream) : launch_scan2400 (sp, stream));
   HIP_TRY (hipEventRecord (e->ev[1], stream));

@@ -176,6 +176,7 @@ typedef struct modes_stats {
   uint64_t demod_rejected_unknown;
   uint64_t candidates;       /* records that left the scan kernel               */
   uint64_t replay_rounds;    /* fixed-point rounds of the device replay          */
+  uint64_t scan_retries;     /* scans repeated with more candidate slots per strip */
 } modes_stats;
 
 typedef struct modes_engine_config {

@@ -114,3 +114,17 @@ def test_icao_cache_chaining_across_runs():
     e.run_host(iq)
     assert_same_messages(e.messages(), exp)
     assert (exp["msg_type"] == 4).sum() + (exp["msg_type"] == 5).sum() + (exp["msg_type"] == 0).sum() > 20
+
+
+def test_strip_overflow_is_rescanned(monkeypatch):
+    """Two candidate slots per strip overflow on any real signal: the engine scans again with more slots until
+    everything fits, and the result is the oracle's."""
+    iq, _ = synth.capture(600_000, 2.4e6, "sc16", seed=12, frames_per_sec=3000, bitflip1=0.1, ap_fraction=0.2)
+    exp, est = oracle_run(iq, "sc16")
+    monkeypatch.setenv("MODES_STRIP_SLOTS", "2")
+    for host_replay in (False, True):
+        e = da.Engine(2400000, da.INPUT_SC16, host_replay=host_replay)
+        e.run_host(iq)
+        assert e.stats()["scan_retries"] >= 1
+        assert_same_messages(e.messages(), exp)
+        assert e.stats()["valid_preamble"] == est["valid_preamble"]
