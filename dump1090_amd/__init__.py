@@ -124,6 +124,7 @@ def lib():
         L.modes_engine_num_messages.argtypes = [C.c_void_p]
         L.modes_engine_messages.restype = C.c_void_p
         L.modes_engine_messages.argtypes = [C.c_void_p]
+        L.modes_engine_format_raw.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]
         L.modes_engine_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.modes_engine_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.modes_engine_block_power.restype = C.c_size_t
@@ -231,6 +232,12 @@ class Engine:
             return np.zeros(0, dtype=MESSAGE_DTYPE)
         buf = (C.c_char * (n * MESSAGE_DTYPE.itemsize)).from_address(self.L.modes_engine_messages(self.h))
         return np.frombuffer(buf, dtype=MESSAGE_DTYPE).copy()
+
+    def format_raw(self, upper_case=False):
+        """RAW text of the last run's messages (bytes): '*<hex>;\\n' per message."""
+        t, n = C.c_char_p(), C.c_size_t()
+        _check(self.L.modes_engine_format_raw(self.h, int(upper_case), C.byref(t), C.byref(n)))
+        return C.string_at(t, n.value) if n.value else b""
 
     def kernel_ms(self):
         """(main, second) kernel durations of the last run in ms (HIP events on the launch stream)."""

@@ -154,6 +154,12 @@ struct modes_engine {
   float dc_A = 0.0f, dc_B = 1.0f, dc_z[2] = { 0.0f, 0.0f };
   uint64_t dc_lead = 0, dc_warm = 0;
   modes_dc_info dc_info;
+  // RAW text of the last run's messages
+  DevBuf<uint32_t> raw_len;
+  DevBuf<uint64_t> raw_off, raw_cs, raw_cv, raw_co;
+  DevBuf<char> raw_text;
+  char *pin_text = nullptr;
+  size_t pin_text_cap = 0;
   // results: the device accept path lands its messages in pinned host memory (one DMA, no staging copies);
   // the host-ordered paths build `messages`
   std::vector<modes_message> messages;
@@ -525,6 +531,8 @@ void modes_engine_destroy (modes_engine *e)
   e->blk_stats.release (); e->small_u32.release (); e->d_messages.release ();
   e->rssi_sum.release (); e->staging.release (); e->tail.release (); e->vp_bitmap.release ();
   e->block_power.release (); e->noise_level.release ();
+  e->raw_len.release (); e->raw_off.release (); e->raw_cs.release (); e->raw_cv.release (); e->raw_co.release (); e->raw_text.release ();
+  if (e->pin_text) (void) hipHostFree (e->pin_text);
   e->dc_mag.release (); e->dc_desc.release (); e->dc_zs.release (); e->dc_ze.release (); e->dc_unm.release ();
   e->d8_trig.release (); e->d8_amb.release (); e->d8_off.release (); e->d8_p0.release (); e->d8_mx.release ();
   e->d8_win_count.release (); e->d8_chunk_rec.release (); e->d8_announce.release (); e->d8_table.release (); e->d8_entry.release ();
@@ -954,6 +962,45 @@ const modes_message *modes_engine_messages (const modes_engine *e)
   if (!e) return nullptr;
   if (e->in_pinned) return e->pin_n ? e->pin_msgs : nullptr;
   return e->messages.empty () ? nullptr : e->messages.data ();
+}
+
+int modes_engine_format_raw (modes_engine *e, int upper_case, const char **text, size_t *len)
+{
+  if (!e || !text || !len) return fail (MODES_E_ARG, "null argument");
+  *text = ""; *len = 0;
+  const size_t n = modes_engine_num_messages (e);
+  if (!n) return MODES_OK;
+  if (n > 0xFFFFFFFFull) return fail (MODES_E_ARG, "too many messages");
+  HIP_TRY (hipSetDevice (e->cfg.device));
+  int rc;
+  if ((rc = e->d_messages.reserve (n)) != MODES_OK) return rc;
+  if (!e->in_pinned)                       // the host-ordered paths hold their messages in host memory only
+    HIP_TRY (hipMemcpy (e->d_messages.p, e->messages.data (), n * sizeof (modes_message), hipMemcpyHostToDevice));
+  const uint32_t nchunks = uint32_t ((n + 1023) / 1024);
+  if ((rc = e->raw_len.reserve (n)) != MODES_OK) return rc;
+  if ((rc = e->raw_off.reserve (n)) != MODES_OK) return rc;
+  if ((rc = e->raw_cs.reserve (nchunks + 1)) != MODES_OK) return rc;
+  if ((rc = e->raw_cv.reserve (nchunks + 1)) != MODES_OK) return rc;
+  if ((rc = e->raw_co.reserve (nchunks + 1)) != MODES_OK) return rc;
+  uint64_t *d_totals = reinterpret_cast<uint64_t *> (e->d_stats) + 24;
+  HIP_TRY (launch_raw_format (e->d_messages.p, uint32_t (n), e->raw_len.p, e->raw_cs.p, e->raw_cv.p, e->raw_co.p, d_totals,
+                              e->raw_off.p, upper_case, nullptr, 0, nullptr));
+  unsigned long long total = 0;
+  HIP_TRY (hipMemcpy (&total, d_totals, sizeof total, hipMemcpyDeviceToHost));
+  if ((rc = e->raw_text.reserve (size_t (total) + 1)) != MODES_OK) return rc;
+  if (total + 1 > e->pin_text_cap) {
+    if (e->pin_text) (void) hipHostFree (e->pin_text);
+    e->pin_text = nullptr; e->pin_text_cap = 0;
+    const size_t want = size_t (total) + size_t (total) / 4 + 4096;
+    HIP_TRY (hipHostMalloc (reinterpret_cast<void **> (&e->pin_text), want, hipHostMallocDefault));
+    e->pin_text_cap = want;
+  }
+  HIP_TRY (launch_raw_format (e->d_messages.p, uint32_t (n), e->raw_len.p, e->raw_cs.p, e->raw_cv.p, e->raw_co.p, d_totals,
+                              e->raw_off.p, upper_case, e->raw_text.p, 1, nullptr));
+  HIP_TRY (hipMemcpy (e->pin_text, e->raw_text.p, size_t (total), hipMemcpyDeviceToHost));
+  e->pin_text[total] = 0;
+  *text = e->pin_text; *len = size_t (total);
+  return MODES_OK;
 }
 
 int modes_engine_get_stats (const modes_engine *e, modes_stats *out)

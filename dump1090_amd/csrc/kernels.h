@@ -34,6 +34,8 @@ hipError_t launch_rssi2400 (int conv, const uint8_t *iq, uint64_t nsamples, cons
                             uint64_t *sum_out, uint32_t nmsg, hipStream_t stream);
 hipError_t launch_convert_float (int conv, const uint8_t *iq, uint16_t *mag, size_t n, float A, float B, float zI0, float zQ0,
                                  float *zI, float *zQ, float *mag_sq, float *z_final, float *power_out, hipStream_t stream);
+hipError_t launch_raw_format (const void *msgs, uint32_t n, uint32_t *len, uint64_t *chunk_sum, uint64_t *chunk_vp,
+                              uint64_t *chunk_ovf, uint64_t *totals, uint64_t *offsets, int upper, char *text, int pass, hipStream_t stream);
 // kernels_dc.hip
 hipError_t launch_dc_chain (int conv, const DcParams &p, uint32_t ndesc, hipStream_t stream);
 hipError_t launch_accept2400 (const AcceptParams &p, hipStream_t stream);

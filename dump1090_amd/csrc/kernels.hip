@@ -1109,6 +1109,51 @@ void emit2400_kernel (const EmitParams p)
   }
 }
 
+// ---- RAW output of the accepted messages: "*<hex>;\n" per message, back to back ----
+// lower case = what raw_out_send() writes to port-30002 clients (ref: src/raw-sbs.c:86-97), upper case = what
+// modeS_user_message() prints with --raw (ref: src/dump1090.c:3086-3097)
+__global__ __launch_bounds__ (256)
+void raw_len_kernel (const MsgOut *msgs, uint32_t n, uint32_t *len)
+{
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) len[i] = 3u + 2u * (msgs[i].msg_bits / 8u);
+}
+
+__global__ __launch_bounds__ (256)
+void raw_format_kernel (const MsgOut *msgs, uint32_t n, const uint64_t *offsets, int upper, char *text)
+{
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const MsgOut &m = msgs[i];
+  char *p = text + offsets[i];
+  const int nb = m.msg_bits / 8;
+  const char a = upper ? 'A' : 'a';
+  *p++ = '*';
+  for (int b = 0; b < nb; b++) {
+    const int hi = m.msg[b] >> 4, lo = m.msg[b] & 15;
+    *p++ = char (hi < 10 ? '0' + hi : a + hi - 10);
+    *p++ = char (lo < 10 ? '0' + lo : a + lo - 10);
+  }
+  *p++ = ';';
+  *p++ = '\n';
+}
+
+// lengths -> offsets (the strip scan kernels serve: one "strip" per message) -> text.  totals[0] receives the text length.
+hipError_t launch_raw_format (const void *msgs, uint32_t n, uint32_t *len, uint64_t *chunk_sum, uint64_t *chunk_vp,
+                              uint64_t *chunk_ovf, uint64_t *totals, uint64_t *offsets, int upper, char *text, int pass, hipStream_t stream)
+{
+  if (n == 0) return hipSuccess;
+  const MsgOut *m = static_cast<const MsgOut *> (msgs);
+  if (pass == 0) {
+    hipLaunchKernelGGL (raw_len_kernel, dim3 ((n + 255) / 256), dim3 (256), 0, stream, m, n, len);
+    hipError_t e = launch_count_scan (len, len, n, chunk_sum, chunk_vp, chunk_ovf, totals, stream);
+    if (e != hipSuccess) return e;
+    return launch_strip_offsets (len, n, chunk_sum, offsets, stream);
+  }
+  hipLaunchKernelGGL (raw_format_kernel, dim3 ((n + 255) / 256), dim3 (256), 0, stream, m, n, offsets, upper, text);
+  return hipGetLastError ();
+}
+
 // `ov` magnitudes of the virtual stream starting at V[at]: with at = nsamples this is what fifo_enqueue keeps for the
 // next block (ref: src/fifo.c:205-211), i.e. the halo of a following shard
 template <int CONV>

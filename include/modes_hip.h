@@ -224,6 +224,12 @@ int  modes_engine_time_scan (modes_engine *e, const void *d_iq, size_t nbytes, i
  * main_ms = the scan kernel (2.0 / 2.4 MS/s) or the window kernel (8 MS/s); second_ms = the 8 MS/s trigger kernel, else 0. */
 int  modes_engine_kernel_ms (const modes_engine *e, float *main_ms, float *second_ms);
 
+/* The last run's messages as RAW text, one "*<hex>;\n" per message in order, formatted on the device:
+ * upper_case = 0: what raw_out_send() sends to RAW-out clients (ref: src/raw-sbs.c:86-97);
+ * upper_case = 1: what modeS_user_message() prints with --raw (ref: src/dump1090.c:3086-3097).
+ * *text points into host memory owned by the engine (valid until the next call), NUL-terminated. */
+int  modes_engine_format_raw (modes_engine *e, int upper_case, const char **text, size_t *len);
+
 size_t               modes_engine_num_messages (const modes_engine *e);
 const modes_message *modes_engine_messages (const modes_engine *e);      /* host memory */
 int                  modes_engine_get_stats (const modes_engine *e, modes_stats *out);
