@@ -47,6 +47,14 @@ WORKLOADS = {
 CONV_ROW = {("uc8", False): 0, ("uc8", True): 1, ("sc16", False): 3, ("sc16", True): 4, ("uc8", "dc"): 2, ("sc16", "dc"): 4}
 
 
+def _cpu_worker(host, rate, fmt, fix_bits, power, dc, also_ac):
+    from oracle import orc
+    o = orc.Oracle(rate, fix_bits=fix_bits, measure_noise=power)
+    o.run_stream(host, orc.INPUT_UC8 if fmt == "uc8" else orc.INPUT_SC16, rate // 1000, compute_power=power, filter_dc=dc,
+                 also_ac=also_ac)
+    os._exit(0)                                # a forked child must not run the parent's GPU teardown
+
+
 def run_workload(name, args, world, rank, local, dev, want_cpu):
     rate, fmt, ekw, traffic, kernel = WORKLOADS[name]
     import torch.distributed as dist
@@ -160,6 +168,27 @@ def run_workload(name, args, world, rank, local, dev, want_cpu):
                "sample": "first %d blocks (%d MiB) of the same recording, oracle/ C restatement, 1 thread"
                          % (nblk, nblk // 4), "msgs": int(len(cpu_msgs)), "prefix_parity": parity}
 
+    if cpu is not None and args.cpu_all_cores:
+        try:
+            # the same sample once per host core, as independent streams (the reference has no intra-stream parallelism:
+            # one reader thread + one demodulator thread, ref: src/dump1090.c:1298,1367): aggregate CPU throughput
+            cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
+            import multiprocessing as mp
+            small = host[: max(8, nblk // 4) * 262144 // host.itemsize]
+            ctx = mp.get_context("fork")
+            t0 = time.perf_counter()
+            procs = [ctx.Process(target=_cpu_worker, args=(small, rate, fmt, ekw.get("fix_bits", 1), power, dc, bool(ekw.get("mode_ac"))))
+                     for _ in range(cores)]
+            for pr in procs:
+                pr.start()
+            for pr in procs:
+                pr.join()
+            adt = time.perf_counter() - t0
+            cpu["all_cores"] = {"value": round(cores * (small.nbytes // bps) / adt / 1e6, 2), "unit": "Msamples/s", "cores": cores,
+                                "sample": "%d independent copies of the first %d MiB, one oracle process per core" % (cores, small.nbytes >> 20)}
+        except Exception as ex:                    # the baseline is a report, never a reason to lose the bench line
+            cpu["all_cores"] = {"error": repr(ex)}
+
     conv_name = da.CONVERTER_NAMES[CONV_ROW[(fmt, "dc" if dc else power)]] + (" (DC block on)" if dc else "")
     return {
         "value": round(value, 1), "ms_per_step": round(step_s * 1e3, 3),
@@ -183,6 +212,8 @@ def main():
                     help="reference = convert_init(fmt, DC off, power off); power = compute_power=1")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu-all-cores", dest="cpu_all_cores", action="store_false",
+                    help="skip the all-host-cores leg of the CPU baseline (independent streams, one per core)")
     ap.add_argument("--no-also", action="store_true", help="skip the companion sc16 line of the default workload")
     ap.add_argument("--traffic", type=float, default=None, help="HBM bytes per launch of the roofline kernel from PMC counters")
     args = ap.parse_args()

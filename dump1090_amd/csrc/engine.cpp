@@ -285,7 +285,7 @@ int prepare_dc (modes_engine *e, const void *d_iq, size_t nbytes, const uint16_t
   const uint64_t n_eff = n + back, lead_eff = (lead - back) / kDcBatch * kDcBatch;   // chains start on the batch grid of the shard
   uint64_t K = n_eff / 65536;
   if (K < 1) K = 1;
-  uint64_t kmax = 256;                                                // one workgroup (four chains) per CU: the chains are issue-bound
+  uint64_t kmax = 512;                                                // two workgroups (four chains each, 65 KB of LDS) per CU
   if (const char *ev = getenv ("MODES_DC_CHUNKS")) kmax = uint64_t (atoll (ev)) ? uint64_t (atoll (ev)) : kmax;
   if (K > kmax) K = kmax;
   const uint64_t L = ((n_eff + K - 1) / K + kDcBatch - 1) / kDcBatch * kDcBatch;

@@ -169,7 +169,7 @@ __device__ __forceinline__ int dc_round (const float *tk, float z0, float B, int
 
 // One chain over t[0 .. cnt): returns z1 behind the last sample, zo[i] = z1 behind sample i.  z0 is uniform.
 // t and zo are 16-byte aligned.
-__device__ __forceinline__ float dc_chain_batch (const float *t, float *zo, int cnt, float z0, float B, int lane, uint32_t &n_guess, uint32_t &n_plain, int &backoff)
+__device__ __forceinline__ float dc_chain_batch (const float *t, float *zo, bool store, int cnt, float z0, float B, int lane, uint32_t &n_guess, uint32_t &n_plain, int &backoff)
 {
   int base = 0, plain = 0;
   while (base < cnt) {
@@ -180,7 +180,7 @@ __device__ __forceinline__ float dc_chain_batch (const float *t, float *zo, int 
       // every lane steps the same chain: a dependent VALU operation of a wave with one active lane takes four times
       // as long as one with all lanes active (tools/ubench/dep_latency2.hip: 35 against 8.6 cycles per step)
       float z = z0;
-      const bool st = lane == 0;
+      const bool st = store && lane == 0;
       int i = 0;
       for (; i < m && ((base + i) & 3); i++) { z = __fadd_rn (t[dcp (base + i)], __fmul_rn (z, B)); if (st) zo[dcp (base + i)] = z; }
       float4 nx = i + 4 <= m ? *reinterpret_cast<const float4 *> (t + dcp (base + i)) : make_float4 (0.0f, 0.0f, 0.0f, 0.0f);
@@ -207,7 +207,7 @@ __device__ __forceinline__ float dc_chain_batch (const float *t, float *zo, int 
       for (int g = 0; g < kDcPer / 4; g++) { const float4 x = src[g]; tk[4 * g] = x.x; tk[4 * g + 1] = x.y; tk[4 * g + 2] = x.z; tk[4 * g + 3] = x.w; }
     }
     const int good = dc_round (tk, z0, B, lane, zt);             // >= 1: lane 0 starts from z0 itself
-    if (lane < good) {
+    if (store && lane < good) {
       float4 *dst = reinterpret_cast<float4 *> (zo + dcp (base + kDcPer * lane));
 #pragma unroll
       for (int g = 0; g < kDcPer / 4; g++) { float4 o; o.x = zt[4 * g]; o.y = zt[4 * g + 1]; o.z = zt[4 * g + 2]; o.w = zt[4 * g + 3]; dst[g] = o; }
@@ -227,7 +227,7 @@ __global__ __launch_bounds__ (256)
 void dc_chain_kernel (const DcParams p)
 {
   __shared__ __attribute__ ((aligned (16))) float s_t[2][kDcBatchLds];   // f * DC_A per channel
-  __shared__ __attribute__ ((aligned (16))) float s_z[4][kDcBatchLds];   // z1 behind every sample, per chain
+  __shared__ __attribute__ ((aligned (16))) float s_z[2][kDcBatchLds];   // z1 behind every sample, lo chains (the hi chains only serve to close the brackets)
   __shared__ float s_uc8[256];
   __shared__ float s_state[4];                                        // I-lo, I-hi, Q-lo, Q-hi behind the last batch
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -274,7 +274,7 @@ void dc_chain_kernel (const DcParams p)
     const bool closed = (wv & 1) && (wv == 1 ? sIlo == sIhi : sQlo == sQhi);     // a hi chain that has met its lo chain
     if (!closed) {
       const long long tc = clock64 ();
-      z = dc_chain_batch (s_t[wv >> 1], s_z[wv], cnt, z, B, lane, n_guess, n_plain, backoff);
+      z = dc_chain_batch (s_t[wv >> 1], s_z[wv >> 1], !(wv & 1), cnt, z, B, lane, n_guess, n_plain, backoff);
       if (lane == 0) {
         s_state[wv] = z;
         if (!(wv & 1) && (wv == 0 ? sIlo == sIhi : sQlo == sQhi)) s_state[wv + 1] = z;   // the closed hi chain follows
@@ -291,7 +291,7 @@ void dc_chain_kernel (const DcParams p)
         const int o = 1024 * g + 4 * tid;
         if (o >= cnt) break;
         const float4 zI = *reinterpret_cast<const float4 *> (&s_z[0][dcp (o)]);
-        const float4 zQ = *reinterpret_cast<const float4 *> (&s_z[2][dcp (o)]);
+        const float4 zQ = *reinterpret_cast<const float4 *> (&s_z[1][dcp (o)]);
         const float zi[4] = { zI.x, zI.y, zI.z, zI.w }, zq[4] = { zQ.x, zQ.y, zQ.z, zQ.w };
         uint32_t m[4];
 #pragma unroll
