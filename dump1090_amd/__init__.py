@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmodes_hip.so")
+LIB_PATH = os.environ.get("MODES_LIB") or os.path.join(_HERE, "libmodes_hip.so")   # MODES_LIB: development builds (tools/build_variant.sh)
 
 INPUT_ILLEGAL, INPUT_UC8, INPUT_SC16, INPUT_SC16Q11 = 0, 1, 2, 3
 MODES_OK = 0

@@ -93,6 +93,7 @@ struct ScanParams {
   const uint16_t *halo;        // `ov` magnitudes that precede sample 0, or nullptr (zeros)
   uint32_t        ov;          // Modes.trailing_samples (ref: src/dump1090.c:734)
   uint32_t        block_samples;
+  uint32_t        block_strips; // block_samples / kStrip when the block is whole strips, else 0 (one block: only strip 0 starts one)
   int32_t         conv;        // Conv
   int32_t         phase_enhance;
   const ErrEntry *short_tab;  int32_t short_n;

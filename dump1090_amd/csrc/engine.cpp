@@ -230,6 +230,7 @@ int fill_scan_params (modes_engine *e, const void *d_iq, size_t nbytes, const ui
   sp->halo = d_halo;
   sp->ov = e->ov;
   sp->block_samples = e->block_samples;
+  sp->block_strips = e->block_samples % kStrip == 0 ? e->block_samples / kStrip : 0;
   sp->conv = e->conv;
   sp->phase_enhance = e->cfg.phase_enhance;
   sp->short_tab = e->tabs.short_tab; sp->short_n = e->tabs.short_n;

@@ -25,6 +25,7 @@ constexpr int kWavesPerBlock = 4;
 constexpr int kGroupSpan = kWavesPerBlock * kStrip;             // positions one workgroup scans
 constexpr int kTileN = 8 * TileChunks<kGroupSpan + kLook2400>::n;
 constexpr int kQ1Seg = 256;
+constexpr uint32_t kSynSkipped = 0x80000000u;      // stage D1 did not slice the candidate: the reference never looks at it
 template <bool PE> struct WaveLds {
   uint16_t q1[kQ1Seg];                              // off | pattern << 12, kQ1Seg candidates at a time
   uint32_t q2[PE ? 5 * 64 : 64];                    // off | (t-4) << 12 | df << 16, one stage-C batch at a time
@@ -164,12 +165,19 @@ void scan2400_kernel (const ScanParams p)
   // ---- candidates in ascending order, kQ1Seg at a time through queue 1 ----
   const int mycnt = __popc (any);
   const int incl = wave_incl_scan (mycnt, lane);
-  const int n1 = __shfl (incl, 63, 64);
+  const int n1 = __builtin_amdgcn_readlane (incl, 63);      // scalar: the loops below branch on the scalar unit
   bool overflow = false;
   uint32_t valid_preamble = 0, nrec = 0;
   Record *out = p.records + size_t (strip) * p.cap;
-  // per-lane results of stage D1 (lane = candidate of the batch)
-  uint32_t r_m0lo = 0, r_m0hi = 0, r_m1lo = 0, r_m1hi = 0, r_syn = 0;
+  // Skip-ahead known inside the strip (ref: src/demod-2400.c:514): behind a message that the reference certainly
+  // reaches and certainly accepts (DF11/17/18 with syndrome 0: score and accept rules ask the ICAO cache nothing,
+  // ref: src/dump1090.c:3309-3353,2440-2578) it never looks at the next msglen*12/5 positions, so candidates there
+  // are dropped before the slicer.  c_end: positions below are certainly skipped; u_end: positions below may be
+  // skipped by a message whose acceptance depends on the ICAO cache or on what earlier strips found (a block's first
+  // strip starts with nothing pending: each demod_2400 call starts at j = 0).
+  int c_end = 0;
+  uint32_t r_m0lo = 0, r_m0hi = 0, r_m1lo = 0, r_m1hi = 0, r_syn = 0;   // per-lane results of stage D1 (lane = candidate of the batch)
+  int u_end = (p.block_strips ? strip % p.block_strips == 0 : strip == 0) ? 0 : kLongBits * 12 / 5;
 
   for (int seg = 0; seg < n1 && !overflow; seg += kQ1Seg) {
     {
@@ -259,7 +267,7 @@ void scan2400_kernel (const ScanParams p)
       valid_preamble += __popcll (__ballot (pass));                                       // ref: :326
       if (pass) atomicOr (&w.vp[off >> 5], 1u << (off & 31));
       const int inc = wave_incl_scan (nent, lane);
-      const int n2 = __shfl (inc, 63, 64);                 // <= kQ2Cap by construction
+      const int n2 = __builtin_amdgcn_readlane (inc, 63);   // <= kQ2Cap by construction
       {
         const int slot = inc - nent;
         for (int k = 0; k < nent; k++) w.q2[slot + k] = ent[k];
@@ -276,6 +284,7 @@ void scan2400_kernel (const ScanParams p)
           const int coff = qe & 0xFFF, t = 4 + int ((qe >> 12) & 7), df = int (qe >> 16);
           const bool longmsg = slice_bytes_for_df (df) == kLongBytes;   // 14 bytes sliced, else 7 (ref: src/demod-2400.c:416-435)
           const bool longcrc = msg_bits_for_df (df) == kLongBits;       // bits the score's CRC runs over
+          if (!PE && coff < c_end) { if (lane == ci) r_syn = kSynSkipped; continue; }
           const uint16_t *m = V + coff + 19;
           // syndrome = XOR of the single-bit syndromes of the set bits (the CRC is linear, ref: src/crc.c:56-61)
           const bool bit0 = slice_at (m, t + 12 * bl) > 0;
@@ -287,6 +296,11 @@ void scan2400_kernel (const ScanParams p)
             if (longcrc) x ^= bit1 ? sbL1 : 0u;
           } else m0 &= (1ull << 56) - 1;
           const uint32_t syn = uint32_t (__builtin_amdgcn_readlane (int (wave_xor_to63 (x)), 63));
+          if (!PE) {
+            const int next = coff + (longcrc ? kLongBits : kShortBits) * 12 / 5 + 1;
+            if (syn == 0 && (df == 17 || df == 18 || df == 11) && coff >= u_end) c_end = next;
+            else u_end = max (u_end, next);
+          }
           if (lane == ci) { r_m0lo = uint32_t (m0); r_m0hi = uint32_t (m0 >> 32); r_m1lo = uint32_t (m1); r_m1hi = uint32_t (m1 >> 32); r_syn = syn; }
         }
         // ---- stage D2: classes, error-table diagnosis, records; one lane per candidate ----
@@ -297,7 +311,7 @@ void scan2400_kernel (const ScanParams p)
         const uint32_t syn = r_syn;
         const u64 m0 = (u64 (r_m0hi) << 32) | r_m0lo, m1 = (u64 (r_m1hi) << 32) | r_m1lo;
         const u64 crc_bits = longcrc ? (m0 | m1) : (m0 & ((1ull << 56) - 1));
-        bool keep = act && crc_bits != 0;                               // all-zero message -> -2 (ref: src/dump1090.c:3295)
+        bool keep = act && crc_bits != 0 && syn != kSynSkipped;                               // all-zero message -> -2 (ref: src/dump1090.c:3295)
         int cls, nerr = 0, b0 = 0, b1 = 0;
         const bool es = df == 17 || df == 18, acq = df == 11;
         const uint32_t key = acq ? (syn & 0xFFFF80u) : syn;

@@ -51,6 +51,19 @@ def test_sc16_phase_enhance_matches_oracle():
     assert gst["valid_preamble"] == est["valid_preamble"] and gst["out_of_phase"] == est["out_of_phase"]
 
 
+@pytest.mark.parametrize("seed", [31, 32])
+def test_dense_traffic_skip_ahead(seed):
+    """Frames nearly back to back: the scan kernel drops candidates inside a message the reference certainly accepts
+    (its skip-ahead, ref: src/demod-2400.c:514) before slicing them; messages and statistics must not notice."""
+    iq, _ = synth.capture(1_500_000, 2.4e6, "sc16", seed=seed, frames_per_sec=6500, ap_fraction=0.3, bitflip1=0.1, n_icao=6)
+    exp, est = oracle_run(iq, "sc16", fix_bits=1)
+    got, gst = engine_run(iq, "sc16", fix_bits=1)
+    assert len(exp) > 1500
+    assert_same_messages(got, exp)
+    for k in ("valid_preamble", "demodulated", "CRC_good", "CRC_bad", "CRC_single_bit_fix", "out_of_phase", "demod_rejected_unknown"):
+        assert gst[k] == est[k], k
+
+
 def test_uc8_lut_as_written_matches_oracle(modes1):
     """BASELINE config 1: modes1.bin at 2.4 MS/s through the reference-selected converter."""
     exp, est = oracle_run(modes1, "uc8")
