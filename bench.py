@@ -78,26 +78,45 @@ def run_workload(name, args, world, rank, local, dev, want_cpu):
     nbytes = recs[0][0].numel() * recs[0][0].element_size()
     eng = da.Engine(rate, fmt_id, device=local, **dict(ekw, compute_power=power))
     stream = torch.cuda.current_stream().cuda_stream
+    # a batch of independent recordings (configs[4]) is decoded by several engines at once, each on its own HIP stream
+    # and host thread: one engine's host-side steps (counts read back, ordered Mode A/C pass) overlap the others' kernels
+    nlanes = min(args.batch_streams, nrec) if nrec > 1 else 1
+    lanes = [(eng, stream)]
+    for _ in range(nlanes - 1):
+        st_ = torch.cuda.Stream(device=dev)
+        lanes.append((da.Engine(rate, fmt_id, device=local, **dict(ekw, compute_power=power)), st_.cuda_stream))
+        lanes[-1] += (st_,)                  # keep the stream object alive
+    pool = None
+    if nlanes > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=nlanes)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def one_step():
+    def run_lane(li):
+        e, st = lanes[li][0], lanes[li][1]
         nm, kms, k2 = 0, 0.0, 0.0
-        for iq, _ in recs:
-            eng.set_icao(None)                # every recording is decoded from a cold ICAO cache
+        for iq, _ in recs[li::nlanes]:
+            e.set_icao(None)                  # every recording is decoded from a cold ICAO cache
             if dc:
-                eng.set_dc_state(0.0, 0.0)    # ... and from convert_init()'s filter state
-            eng.run_device(iq.data_ptr(), nbytes, stream=stream)
-            nm += eng.num_messages()
-            a, b = eng.kernel_ms()
+                e.set_dc_state(0.0, 0.0)      # ... and from convert_init()'s filter state
+            e.run_device(iq.data_ptr(), nbytes, stream=st)
+            nm += e.num_messages()
+            a, b = e.kernel_ms()
             if dc:                            # the chain kernel dominates there; the scan kernel is reported second
-                a, b = eng.dc_info()["chain_ms"], a
+                a, b = e.dc_info()["chain_ms"], a
             kms += a
             k2 += b
         return nm, kms, k2
+
+    def one_step():
+        if pool is None:
+            return run_lane(0)
+        parts = list(pool.map(run_lane, range(nlanes)))
+        return tuple(sum(x[i] for x in parts) for i in range(3))
 
     for _ in range(args.warmup):
         one_step()
@@ -115,8 +134,9 @@ def run_workload(name, args, world, rank, local, dev, want_cpu):
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    msgs = eng.messages()
-    stats = eng.stats()
+    last_eng = lanes[(nrec - 1) % nlanes][0]          # the engine that decoded recs[-1] last
+    msgs = last_eng.messages()
+    stats = last_eng.stats()
     nmsg = torch.tensor([nm], device=dev, dtype=torch.int64)
     if world > 1:
         dist.all_reduce(nmsg)
@@ -142,7 +162,7 @@ def run_workload(name, args, world, rank, local, dev, want_cpu):
     if k2:
         roofline["second_kernel"] = {"kernel": "scan2400_kernel" if dc else "d8_trig_kernel", "kernel_ms": round(k2 / args.steps / nrec, 4)}
     if dc:
-        roofline["dc_chain"] = eng.dc_info()
+        roofline["dc_chain"] = last_eng.dc_info()
 
     cpu = None
     if want_cpu:
@@ -195,7 +215,8 @@ def run_workload(name, args, world, rank, local, dev, want_cpu):
         "config": {"workload": "%s: synthetic %.1f MS/s %s IQ, %d x %.2f GiB per GPU, injected DF11/DF17 frames at mixed SNR"
                                % (name, rate / 1e6, fmt, nrec, nbytes / (1 << 30)),
                    "converter": conv_name, "demod": "demod_%d%s" % (rate // 1000, "+demod_2400_AC" if ekw.get("mode_ac") else ""),
-                   "fix_bits": ekw.get("fix_bits", 1), "frames_injected_per_gpu": int(sum(len(i["pos"]) for _, i in recs))},
+                   "fix_bits": ekw.get("fix_bits", 1), "frames_injected_per_gpu": int(sum(len(i["pos"]) for _, i in recs)),
+                   "concurrent_engines": nlanes},
         "msgs": int(nmsg.item()), "msgs_per_s": round(int(nmsg.item()) / step_s, 1),
         "valid_preamble": stats["valid_preamble"], "candidates": stats["candidates"],
         "roofline": roofline, "cpu_baseline": cpu, "gen_seconds": round(gen_s, 1)}
@@ -211,6 +232,7 @@ def main():
     ap.add_argument("--converter", default="reference", choices=["reference", "power"],
                     help="reference = convert_init(fmt, DC off, power off); power = compute_power=1")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (rank 0, N=1)")
+    ap.add_argument("--batch-streams", type=int, default=4, help="engines (HIP streams) that share a batch of recordings")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-cpu-all-cores", dest="cpu_all_cores", action="store_false",
                     help="skip the all-host-cores leg of the CPU baseline (independent streams, one per core)")

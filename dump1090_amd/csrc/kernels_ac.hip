@@ -67,20 +67,48 @@ void scanac2400_kernel (const ScanParams p)
   __builtin_amdgcn_s_waitcnt (0xc07f);
   __builtin_amdgcn_wave_barrier ();
 
-  Record *out = p.records + size_t (strip) * p.cap;
-  uint32_t nrec = 0;
-  bool overflow = false;
-  for (int base = 0; base < n1 && !overflow; base += 64) {
+  // ---- F2: the bracket's second pulse at +87*14 clocks with the same tests (ref: :105-124); survivors (few) are
+  //      compacted in place before the 20-slot loop, so that loop runs with full lanes ----
+  int n2 = 0;
+  for (int base = 0; base < n1; base += 64) {
     const int qi = base + lane;
-    bool hit = false;
-    uint32_t code = 0, f2_clock = 0;
+    bool ok = false;
     int off = 0;
     if (qi < n1) {
       off = w.q1[qi];
       const uint32_t f1 = uint32_t (jb0) + uint32_t (off);     // index into the block's mag_buf
       const uint16_t *m = V + off;                             // m[k] == data[f1 + k]
-      const uint32_t f1_level = (uint32_t (m[0]) + m[1]) / 2;
       // sub-sample position of F1 from the energy split of its two samples (ref: :97-108)
+      const float pa = __fmul_rn (float (m[0]), float (m[0])), pb = __fmul_rn (float (m[1]), float (m[1]));
+      const float frac = __fdiv_rn (pb, __fadd_rn (pa, pb));
+      const float pos = __fmul_rn (25.0f, __fadd_rn (float (f1), __fmul_rn (frac, frac)));
+      const uint32_t f1_clock = uint32_t (__dadd_rn (double (pos), 0.5));
+      const uint32_t f2 = (f1_clock + 87 * 14) / 25;
+      const uint16_t *n = m + (int (f2) - int (f1));
+      ok = n[-1] < n[0] && !(n[2] > n[0] || n[2] > n[1]);                                    // ref: :112-124
+      const uint32_t f2_level = (uint32_t (n[0]) + n[1]) / 2;
+      ok = ok && !(noise_level * 2 > f2_level);
+    }
+    const u64 bm = __ballot (ok);
+    if (ok) w.q1[n2 + __popcll (bm & ((1ull << lane) - 1))] = uint16_t (off);                // n2 + rank <= qi: in place
+    n2 += __popcll (bm);
+  }
+  __builtin_amdgcn_s_waitcnt (0xc07f);
+  __builtin_amdgcn_wave_barrier ();
+
+  Record *out = p.records + size_t (strip) * p.cap;
+  uint32_t nrec = 0;
+  bool overflow = false;
+  for (int base = 0; base < n2 && !overflow; base += 64) {
+    const int qi = base + lane;
+    bool hit = false;
+    uint32_t code = 0, f2_clock = 0;
+    int off = 0;
+    if (qi < n2) {
+      off = w.q1[qi];
+      const uint32_t f1 = uint32_t (jb0) + uint32_t (off);
+      const uint16_t *m = V + off;
+      const uint32_t f1_level = (uint32_t (m[0]) + m[1]) / 2;
       const float pa = __fmul_rn (float (m[0]), float (m[0])), pb = __fmul_rn (float (m[1]), float (m[1]));
       const float frac = __fdiv_rn (pb, __fadd_rn (pa, pb));
       const float pos = __fmul_rn (25.0f, __fadd_rn (float (f1), __fmul_rn (frac, frac)));
@@ -88,10 +116,8 @@ void scanac2400_kernel (const ScanParams p)
       f2_clock = f1_clock + 87 * 14;
       const uint32_t f2 = f2_clock / 25;
       const uint16_t *n = m + (int (f2) - int (f1));
-      bool ok = n[-1] < n[0] && !(n[2] > n[0] || n[2] > n[1]);                              // ref: :112-124
       const uint32_t f2_level = (uint32_t (n[0]) + n[1]) / 2;
-      ok = ok && !(noise_level * 2 > f2_level);
-      if (ok) {
+      {
         const uint32_t top = f1_level > f2_level ? f1_level : f2_level;
         const float mid = __fsqrt_rn (float (noise_level * top));                            // ref: :132
         const uint32_t sig_thr = uint32_t (__dadd_rn (__dmul_rn (double (mid), 1.41421356237309504880), 0.5));
