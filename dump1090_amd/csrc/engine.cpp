@@ -166,7 +166,8 @@ struct modes_engine {
   modes_message *pin_msgs = nullptr;
   size_t pin_cap = 0, pin_n = 0;
   bool in_pinned = false;
-  unsigned long long *pin_small = nullptr;   // 32 words: totals and statistics read back once per run
+  unsigned long long *pin_small = nullptr;   // 32 words: totals and statistics read back once per round; word 32: `changed`
+  uint32_t *pin_cache = nullptr;             // the ICAO cache behind the last block, read back with them
   modes_stats stats;
 };
 
@@ -200,7 +201,8 @@ int setup_tables (modes_engine *e)
     else                    { t.long_tab = p;  t.long_n = int (d.size ()); t.bloom_long = pb; }
   }
   HIP_TRY (hipMalloc (reinterpret_cast<void **> (&e->d_stats), 32 * sizeof (unsigned long long)));
-  HIP_TRY (hipHostMalloc (reinterpret_cast<void **> (&e->pin_small), 32 * sizeof (unsigned long long), hipHostMallocDefault));
+  HIP_TRY (hipHostMalloc (reinterpret_cast<void **> (&e->pin_small), 40 * sizeof (unsigned long long), hipHostMallocDefault));
+  HIP_TRY (hipHostMalloc (reinterpret_cast<void **> (&e->pin_cache), kIcaoSlots * sizeof (uint32_t), hipHostMallocDefault));
   if (e->cfg.sample_rate == 2000000) {
     std::vector<uint16_t> l10 (65536);
     build_log10_lut (l10.data ());
@@ -411,27 +413,28 @@ int run_accept_on_device (modes_engine *e, const ScanParams &sp, uint64_t first_
   ap.vp_bitmap = e->mode == 2400 ? e->vp_bitmap.p : nullptr; ap.changed = d_changed;
   ap.mode = e->mode;
 
+  // Every round queues what the last round needs behind it (snapshots, totals, the cache read-back), so the host waits
+  // once per round and the round that finds nothing changed is already the complete result.
+  uint64_t *d_totals = reinterpret_cast<uint64_t *> (e->d_stats);
+  uint32_t *pin_changed = reinterpret_cast<uint32_t *> (e->pin_small + 32);
   uint32_t rounds = 0;
   for (;;) {
-    uint32_t changed = 0;
     HIP_TRY (hipMemsetAsync (d_changed, 0, sizeof (uint32_t), stream));
     HIP_TRY (launch_accept2400 (ap, stream));
-    HIP_TRY (hipMemcpyAsync (&changed, d_changed, sizeof changed, hipMemcpyDeviceToHost, stream));
+    HIP_TRY (hipMemcpyAsync (pin_changed, d_changed, sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY (launch_snapshots (e->delta.p, nblocks, d_cache_in, e->chunk_last.p, e->chunk_entry.p, e->snap_in.p, d_cache_out, stream));
+    // totals of accepted messages and the block statistics, read back together with the scan's totals
+    HIP_TRY (launch_count_scan (e->acc_counts.p, e->vp_counts.p, sp.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p, d_totals + 4, stream));
+    HIP_TRY (launch_blk_stats_sum (e->blk_stats.p, nblocks, e->d_stats + 8, stream));
+    HIP_TRY (hipMemcpyAsync (e->pin_small, d_totals, 32 * sizeof (unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIP_TRY (hipMemcpyAsync (e->pin_cache, d_cache_out, kIcaoSlots * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
     HIP_TRY (hipStreamSynchronize (stream));
     rounds++;
-    HIP_TRY (launch_snapshots (e->delta.p, nblocks, d_cache_in, e->chunk_last.p, e->chunk_entry.p, e->snap_in.p, d_cache_out, stream));
-    if (!changed) break;
+    if (!*pin_changed) break;
     if (rounds > 256) return fail (MODES_E_HIP, "accept pass did not reach its fixed point in 256 rounds");
   }
   e->stats.replay_rounds = rounds;
-
-  // totals of accepted messages and the block statistics, read back together with the scan's totals: one sync
-  uint64_t *d_totals = reinterpret_cast<uint64_t *> (e->d_stats);
-  HIP_TRY (launch_count_scan (e->acc_counts.p, e->vp_counts.p, sp.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p, d_totals + 4, stream));
-  HIP_TRY (launch_blk_stats_sum (e->blk_stats.p, nblocks, e->d_stats + 8, stream));
-  HIP_TRY (hipMemcpyAsync (e->pin_small, d_totals, 32 * sizeof (unsigned long long), hipMemcpyDeviceToHost, stream));
-  HIP_TRY (hipMemcpyAsync (e->cache.raw (), d_cache_out, kIcaoSlots * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
-  HIP_TRY (hipStreamSynchronize (stream));
+  memcpy (e->cache.raw (), e->pin_cache, kIcaoSlots * sizeof (uint32_t));
   (void) hipEventElapsedTime (&e->kernel_ms[0], e->ev[0], e->ev[1]);
   e->kernel_ms[1] = 0;
   const unsigned long long *st = e->pin_small, *tot = e->pin_small + 4, *sum = e->pin_small + 8;
@@ -548,6 +551,7 @@ void modes_engine_destroy (modes_engine *e)
   if (e->tabs.crc_table) (void) hipFree (e->tabs.crc_table);
   if (e->d_stats) (void) hipFree (e->d_stats);
   if (e->pin_small) (void) hipHostFree (e->pin_small);
+  if (e->pin_cache) (void) hipHostFree (e->pin_cache);
   if (e->pin_msgs) (void) hipHostFree (e->pin_msgs);
   for (hipEvent_t ev : e->ev) if (ev) (void) hipEventDestroy (ev);
   delete e;

@@ -1009,15 +1009,20 @@ hipError_t launch_strip_offsets (const uint32_t *acc_counts, uint32_t nstrips, c
 
 __device__ __forceinline__ uint32_t bcast (uint32_t v, int l) { return uint32_t (__builtin_amdgcn_readlane (int (v), l)); }
 
+constexpr int kEmitStrips = 16;
+
 template <int CONV>
 __global__ __launch_bounds__ (256)
 void emit2400_kernel (const EmitParams p)
 {
-  const uint32_t strip = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // a wave looks at kEmitStrips strips at once: most hold no accepted message
+  const uint32_t strip_base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kEmitStrips;
   const int lane = threadIdx.x & 63;
-  if (strip >= p.nstrips) return;
-  const uint32_t nacc = p.acc_counts[strip];
-  if (!nacc) return;
+  if (strip_base >= p.nstrips) return;
+  const uint32_t cnt = (lane < kEmitStrips && strip_base + lane < p.nstrips) ? p.acc_counts[strip_base + lane] : 0u;
+  for (u64 sm = __ballot (cnt != 0); sm; sm &= sm - 1) {
+  const uint32_t strip = strip_base + uint32_t (__builtin_ctzll (sm));
+  const uint32_t nacc = bcast (cnt, __builtin_ctzll (sm));
   MsgOut *out = reinterpret_cast<MsgOut *> (p.messages) + p.offsets[strip];
   const Record *recs = p.records + size_t (strip) * p.cap;
   const uint32_t nrec = p.counts[strip];
@@ -1120,6 +1125,7 @@ void emit2400_kernel (const EmitParams p)
         *reinterpret_cast<uint2 *> (dst + 12) = o3;
       }
     }
+  }
   }
 }
 
@@ -1349,7 +1355,7 @@ hipError_t launch_snap_broadcast (const uint32_t *cache_in, uint32_t nblocks, ui
 hipError_t launch_emit2400 (const EmitParams &p, hipStream_t stream)
 {
   if (p.nstrips == 0) return hipSuccess;
-  const dim3 grid ((p.nstrips + 3) / 4), block (256);
+  const dim3 grid ((p.nstrips + 4 * kEmitStrips - 1) / (4 * kEmitStrips)), block (256);
   switch (p.conv) {
     case kConvUc8Lut: case kConvUc8LutPower: hipLaunchKernelGGL (emit2400_kernel<kConvUc8Lut>, grid, block, 0, stream, p); break;
     case kConvUc8Generic:     hipLaunchKernelGGL (emit2400_kernel<kConvUc8Generic>, grid, block, 0, stream, p); break;
