@@ -70,11 +70,8 @@ struct TrigLds {
 };
 
 struct WinLds {
-  union {                                   // the magnitudes are dead once the differences are formed
-    uint16_t tile[kWinTile];
-    uint32_t c[(224 + 1) * 8];
-  };
-  int32_t  dw[kWinRows * 8 + 8];
+  uint16_t tile[kWinTile];                  // magnitudes; differences are formed from them where they are needed
+  uint32_t c[(224 + 1) * 8];
   uint32_t tot[64];
   int32_t  match[kD8Win];
   uint8_t  par[kD8Win + 8];
@@ -134,9 +131,21 @@ void d8_trig_kernel (const D8Params q, uint64_t strip_limit)
   __builtin_amdgcn_s_waitcnt (0xc07f);
   __builtin_amdgcn_wave_barrier ();
 
-  for (int idx = lane; idx < kTrigRows * 8; idx += 64) {
-    const int d = dprime_tile (q, w.tile, x0, g0 + idx);
-    w.c[idx] = uint32_t (d < 0 ? -d : d);
+  // `plain`: every difference of the strip is m[j] - m[j+4] inside one block of the stream (see d8_window_kernel)
+  const long long Plo = g0 - kD8LookAhead, Phi = Plo + kTrigRows * 8;
+  bool plain = Plo >= 0 && uint64_t (Phi) + 4 < q.T;
+  if (plain && q.bshift < 63) plain = (uint64_t (Plo) >> q.bshift) == ((uint64_t (Phi) + 4) >> q.bshift);
+  if (plain) {
+    const uint16_t *t = w.tile + int (Plo - x0);
+    for (int idx = lane; idx < kTrigRows * 8; idx += 64) {
+      const int d = int (t[idx]) - int (t[idx + 4]);
+      w.c[idx] = uint32_t (d < 0 ? -d : d);
+    }
+  } else {
+    for (int idx = lane; idx < kTrigRows * 8; idx += 64) {
+      const int d = dprime_tile (q, w.tile, x0, g0 + idx);
+      w.c[idx] = uint32_t (d < 0 ? -d : d);
+    }
   }
   __builtin_amdgcn_s_waitcnt (0xc07f);
   __builtin_amdgcn_wave_barrier ();
@@ -319,30 +328,32 @@ void d8_window_kernel (const D8Params q)
     const uint64_t blkc = q.bshift >= 63 ? 0 : done >> q.bshift;
     const uint64_t mlen_c = min (B, q.T - blkc * B);
     const long long fill_g = (long long) (blkc * B + mlen_c) + kD8LookAhead;
-    for (int idx = lane; idx < kWinRows * 8; idx += 64) {
+    // D'[gbase + idx]; `plain`: every difference of the window is m[j] - m[j+4] inside one block of the stream (no block
+    // edge, no carried-in differences, nothing beyond what the call wrote) -- all but a few windows per block
+    const long long Plo = gbase - kD8LookAhead, Phi = Plo + kWinRows * 8 + 8;
+    bool plain = Plo >= 0 && uint64_t (Phi) + 4 < q.T && gbase + kWinRows * 8 + 8 < fill_g;
+    if (plain && q.bshift < 63) plain = (uint64_t (Plo) >> q.bshift) == ((uint64_t (Phi) + 4) >> q.bshift);
+    const int tbase = int (Plo - x0);                                        // tile index of the sample behind D'[gbase]
+    auto dval = [&] (int idx) -> int {
+      if (plain) return int (w.tile[tbase + idx]) - int (w.tile[tbase + idx + 4]);
       const long long g = gbase + idx;
-      int d;
-      if (g < fill_g) d = dprime_tile (q, w.tile, x0, g);
-      else {
-        // beyond what this call wrote: the buffer still holds what the previous call put at that index, or the
-        // zeros it was allocated with (ref: :106-123, 208-215, 509)
-        d = 0;
-        const uint64_t jj = uint64_t (g - kD8LookAhead) - blkc * B;
-        if (blkc >= 1 && jj < B && q.bshift < 63) {
-          const long long xp = (long long) ((blkc - 1) * B + jj);
-          const uint16_t va = mag_of_V<CONV> (q.sp.iq, q.sp.nsamples, q.sp.halo, q.sp.ov, q.sp.block_samples, q.sp.lut256, xp);
-          d = va;
-          if (jj + 4 < B) d -= mag_of_V<CONV> (q.sp.iq, q.sp.nsamples, q.sp.halo, q.sp.ov, q.sp.block_samples, q.sp.lut256, xp + 4);
-        }
+      if (g < fill_g) return dprime_tile (q, w.tile, x0, g);
+      // beyond what this call wrote: the buffer still holds what the previous call put at that index, or the
+      // zeros it was allocated with (ref: :106-123, 208-215, 509)
+      int d = 0;
+      const uint64_t jj = uint64_t (g - kD8LookAhead) - blkc * B;
+      if (blkc >= 1 && jj < B && q.bshift < 63) {
+        const long long xp = (long long) ((blkc - 1) * B + jj);
+        const uint16_t va = mag_of_V<CONV> (q.sp.iq, q.sp.nsamples, q.sp.halo, q.sp.ov, q.sp.block_samples, q.sp.lut256, xp);
+        d = va;
+        if (jj + 4 < B) d -= mag_of_V<CONV> (q.sp.iq, q.sp.nsamples, q.sp.halo, q.sp.ov, q.sp.block_samples, q.sp.lut256, xp + 4);
       }
-      w.dw[idx] = d;
-    }
-    __builtin_amdgcn_s_waitcnt (0xc07f);
-    __builtin_amdgcn_wave_barrier ();
+      return d;
+    };
 
-    // phase sums of steps s .. s+167: rows m = s+1 .. s+223 <-> dw rows 5 .. 227
+    // phase sums of steps s .. s+167: rows m = s+1 .. s+223 <-> difference rows 5 .. 227
     for (int idx = lane; idx < 224 * 8; idx += 64) {
-      const int d = idx < 223 * 8 ? w.dw[5 * 8 + idx] : 0;
+      const int d = idx < 223 * 8 ? dval (5 * 8 + idx) : 0;
       w.c[idx] = uint32_t (d < 0 ? -d : d);
     }
     __builtin_amdgcn_s_waitcnt (0xc07f);
@@ -390,7 +401,7 @@ void d8_window_kernel (const D8Params q)
         bool bit = false;
         if (kb < nbits) {
           const int o = int (g + 8 * kb - gbase);
-          bit = (w.dw[o - 1] + w.dw[o] + w.dw[o + 1]) >= 0;
+          bit = (dval (o - 1) + dval (o) + dval (o + 1)) >= 0;
         }
         S[pass][h] = __ballot (bit);
       }
