@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <mutex>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "../../include/modes_hip.h"
@@ -92,6 +93,25 @@ struct DevBuf {
   void release () { if (p) (void) hipFree (p); p = nullptr; cap = 0; }
 };
 
+// grow-only pinned host memory: read-backs land there in one DMA (pageable targets are staged piecewise by the runtime)
+template <typename T>
+struct PinBuf {
+  T *p = nullptr;
+  size_t cap = 0;
+  int reserve (size_t n)
+  {
+    if (n <= cap) return MODES_OK;
+    if (p) (void) hipHostFree (p);
+    p = nullptr; cap = 0;
+    size_t want = n + n / 4 + 1024;
+    hipError_t e = hipHostMalloc (reinterpret_cast<void **> (&p), want * sizeof (T), hipHostMallocDefault);
+    if (e != hipSuccess) return fail (MODES_E_NOMEM, "hipHostMalloc(%zu bytes): %s", want * sizeof (T), hipGetErrorString (e));
+    cap = want;
+    return MODES_OK;
+  }
+  void release () { if (p) (void) hipHostFree (p); p = nullptr; cap = 0; }
+};
+
 uint32_t trailing_samples (uint32_t rate)     // ref: src/dump1090.c:734
 {
   return uint32_t ((8 + 112 + 16) * 1E-6 * rate);
@@ -144,6 +164,9 @@ struct modes_engine {
   DevBuf<int64_t> d8_win_start, d8_small;
   DevBuf<D8Window> d8_windows, d8_win_packed;
   DevBuf<Record> d8_records, d8_rec_packed;
+  PinBuf<D8Window> pin_wins;
+  PinBuf<Record> pin_recs;
+  PinBuf<uint32_t> pin_bits;                  // announce bitmap as the run starts with it
   unsigned long long *d_stats = nullptr;
   uint32_t cap = 0;
   // float converters with the DC block on (kernels_dc.hip): V = [overlap | magnitudes] of the shard in HBM
@@ -542,6 +565,7 @@ void modes_engine_destroy (modes_engine *e)
   e->d8_win_count.release (); e->d8_chunk_rec.release (); e->d8_announce.release (); e->d8_table.release (); e->d8_entry.release ();
   e->d8_win_start.release (); e->d8_small.release (); e->d8_windows.release (); e->d8_win_packed.release ();
   e->d8_records.release (); e->d8_rec_packed.release ();
+  e->pin_wins.release (); e->pin_recs.release (); e->pin_bits.release ();
   if (e->tabs.short_tab) (void) hipFree (e->tabs.short_tab);
   if (e->tabs.long_tab) (void) hipFree (e->tabs.long_tab);
   if (e->tabs.lut256) (void) hipFree (e->tabs.lut256);
@@ -844,13 +868,17 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   // addresses the run can know: what the cache starts with, plus every address the window kernel sees announced
   q.announce = e->d8_announce.p;
   {
-    std::vector<uint32_t> bits ((1u << 24) / 32, 0u);
-    for (uint32_t i = 0; i < kIcaoSlots; i++) {
-      const uint32_t a = e->cache.raw ()[i] & 0xFFFFFFu;           // the non-ICAO flag (bit 24) never matches a 24-bit test
-      if (e->cache.raw ()[i] && e->cache.raw ()[i] < (1u << 24)) bits[a >> 5] |= 1u << (a & 31);
+    // the bitmap is cleared on the device; only the addresses the starting cache holds travel (4 KB)
+    HIP_TRY (hipMemsetAsync (q.announce, 0, ((1u << 24) / 32) * sizeof (uint32_t), stream));
+    if ((rc = e->pin_bits.reserve (kIcaoSlots)) != MODES_OK) return rc;
+    if ((rc = e->small_u32.reserve (2 * kIcaoSlots + 16)) != MODES_OK) return rc;
+    uint32_t nseed = 0;
+    for (uint32_t i = 0; i < kIcaoSlots; i++)                      // the non-ICAO flag (bit 24) never matches a 24-bit test
+      if (e->cache.raw ()[i] && e->cache.raw ()[i] < (1u << 24)) e->pin_bits.p[nseed++] = e->cache.raw ()[i] & 0xFFFFFFu;
+    if (nseed) {
+      HIP_TRY (hipMemcpyAsync (e->small_u32.p, e->pin_bits.p, nseed * sizeof (uint32_t), hipMemcpyHostToDevice, stream));
+      HIP_TRY (launch_d8_seed (q.announce, e->small_u32.p, nseed, stream));
     }
-    HIP_TRY (hipMemcpyAsync (q.announce, bits.data (), bits.size () * sizeof (uint32_t), hipMemcpyHostToDevice, stream));
-    HIP_TRY (hipStreamSynchronize (stream));
   }
   HIP_TRY (launch_d8_chain (q, 0ull, 0ll, d_pre, d_pending, stream));
   HIP_TRY (hipEventRecord (e->ev[0], stream));
@@ -876,10 +904,12 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   if ((rc = e->d8_rec_packed.reserve (nrec + 1)) != MODES_OK) return rc;
   HIP_TRY (hipMemcpyAsync (e->d8_off.p, off.data (), off.size () * sizeof (uint64_t), hipMemcpyHostToDevice, stream));
   HIP_TRY (launch_d8_gather (q, e->d8_off.p, e->d8_off.p + nchunks + 1, e->d8_win_packed.p, e->d8_rec_packed.p, stream));
-  std::vector<D8Window> wins (nwin);
-  std::vector<Record> recs (nrec + 1);
-  HIP_TRY (hipMemcpyAsync (wins.data (), e->d8_win_packed.p, nwin * sizeof (D8Window), hipMemcpyDeviceToHost, stream));
-  if (nrec) HIP_TRY (hipMemcpyAsync (recs.data (), e->d8_rec_packed.p, nrec * sizeof (Record), hipMemcpyDeviceToHost, stream));
+  if ((rc = e->pin_wins.reserve (nwin)) != MODES_OK) return rc;
+  if ((rc = e->pin_recs.reserve (nrec + 1)) != MODES_OK) return rc;
+  const D8Window *wins = e->pin_wins.p;
+  const Record *recs = e->pin_recs.p;
+  HIP_TRY (hipMemcpyAsync (e->pin_wins.p, e->d8_win_packed.p, nwin * sizeof (D8Window), hipMemcpyDeviceToHost, stream));
+  if (nrec) HIP_TRY (hipMemcpyAsync (e->pin_recs.p, e->d8_rec_packed.p, nrec * sizeof (Record), hipMemcpyDeviceToHost, stream));
   HIP_TRY (hipStreamSynchronize (stream));
 
   Pass8000Stats ps;
@@ -892,7 +922,11 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
     if (m_start >= 0) { rpos.push_back (blkc * B + uint64_t (m_start)); rlen.push_back (uint32_t (slen)); rmsg.push_back (uint32_t (e->messages.size ())); }
     e->messages.push_back (m);
   };
-  accept_pass_8000 (wins.data (), nwin, recs.data (), B, q.bshift, T, e->ov, first_sample, e->cfg.sample_rate, hooks, ps);
+  rpos.reserve (nwin); rlen.reserve (nwin); rmsg.reserve (nwin);
+  e->messages.reserve (nwin);
+  const auto t_host0 = std::chrono::steady_clock::now ();
+  accept_pass_8000 (wins, nwin, recs, B, q.bshift, T, e->ov, first_sample, e->cfg.sample_rate, hooks, ps);
+  if (getenv ("MODES_TIMING")) fprintf (stderr, "run_8000: ordered pass over %zu windows / %zu records: %.3f ms, %zu messages\n", size_t (nwin), size_t (nrec), std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - t_host0).count (), e->messages.size ());
   e->stats.valid_preamble = ps.valid_preamble; e->stats.demodulated = ps.demodulated;
   e->stats.CRC_good = ps.CRC_good; e->stats.CRC_bad = ps.CRC_bad; e->stats.CRC_single_bit_fix = ps.CRC_single_bit_fix;
   e->stats.CRC_two_bits_fix = ps.CRC_two_bits_fix; e->stats.CRC_fixed = ps.CRC_single_bit_fix + ps.CRC_two_bits_fix;

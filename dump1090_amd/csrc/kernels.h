@@ -24,6 +24,7 @@ hipError_t launch_d8_chain (const D8Params &q, unsigned long long trig_tail, lon
                             long long *pending_out, hipStream_t stream);
 hipError_t launch_d8_windows (const D8Params &q, hipStream_t stream);
 hipError_t launch_d8_tail (const D8Params &q, int32_t *dnext, hipStream_t stream);
+hipError_t launch_d8_seed (uint32_t *announce, const uint32_t *addr, uint32_t n, hipStream_t stream);
 hipError_t launch_d8_count (const D8Params &q, uint32_t *chunk_rec, hipStream_t stream);
 hipError_t launch_d8_gather (const D8Params &q, const uint64_t *win_off, const uint64_t *rec_off, D8Window *win_out,
                              Record *rec_out, hipStream_t stream);

@@ -71,8 +71,6 @@ struct TrigLds {
 
 struct WinLds {
   uint16_t tile[kWinTile];                  // magnitudes; differences are formed from them where they are needed
-  uint32_t c[(224 + 1) * 8];
-  uint32_t tot[64];
   int32_t  match[kD8Win];
   uint8_t  par[kD8Win + 8];
   uint16_t lut[256];
@@ -351,27 +349,41 @@ void d8_window_kernel (const D8Params q)
       return d;
     };
 
-    // phase sums of steps s .. s+167: rows m = s+1 .. s+223 <-> difference rows 5 .. 227
-    for (int idx = lane; idx < 224 * 8; idx += 64) {
-      const int d = idx < 223 * 8 ? dval (5 * 8 + idx) : 0;
-      w.c[idx] = uint32_t (d < 0 ? -d : d);
-    }
-    __builtin_amdgcn_s_waitcnt (0xc07f);
-    __builtin_amdgcn_wave_barrier ();
-    column_prefix (w.c, w.tot, 28, lane);
-
-    // best phase of every step (first maximum wins, ref: :305-307); the match follows the opening step's phase
+    // phase sums of steps s .. s+167 (ref: :235-271): ph_i(t) = sum over rows t .. t+55 of |D'| in column i, rows counted
+    // from difference row 5.  Lane = segment * 8 + column: eight segments of 21 steps slide their own window sum, the
+    // eight columns of a step sit in eight neighbouring lanes.
+    const int col = lane & 7, t0 = (lane >> 3) * 21;
     int start_phase = 0;
-    for (int it = 0; it < 3; it++) {
-      const int t = it * 64 + lane;
-      int best = 0; uint32_t mxv = 0, ph[8];
-      if (t < kD8Win) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) { ph[i] = w.c[(t + 56) * 8 + i] - w.c[t * 8 + i]; if (ph[i] > mxv) { mxv = ph[i]; best = i; } }
-        w.par[t] = uint8_t (best);
+    // one step: the best phase (the first maximum wins, ref: :305-307) and the match along the opening step's phase
+    auto step_out = [&] (int t, int u, uint32_t psum) {
+      uint32_t key = (psum << 3) | uint32_t (7 - col);
+      key = max (key, dpp_mov<0xB1> (key));              // quad_perm [1,0,3,2]
+      key = max (key, dpp_mov<0x4E> (key));              // quad_perm [2,3,0,1]
+      key = max (key, dpp_mov<0x141> (key));             // row_half_mirror: the other quad of the eight
+      const int best = 7 - int (key & 7u);
+      if (u == 0) start_phase = __builtin_amdgcn_readfirstlane (best);      // lane 0: step 0 of the window
+      if (col == 0) w.par[t] = uint8_t (best);
+      if (col == start_phase) w.match[t] = int (psum);
+    };
+    if (plain) {
+      const uint16_t *tp = w.tile + tbase + 5 * 8 + col + 8 * t0;            // row r of this lane's segment: tp[8 r], tp[8 r + 4]
+      uint32_t psum = 0;
+#pragma unroll 8
+      for (int r = 0; r < 56; r++) { const int d = int (tp[8 * r]) - int (tp[8 * r + 4]); psum += uint32_t (d < 0 ? -d : d); }
+#pragma unroll 7
+      for (int u = 0; u < 21; u++) {
+        step_out (t0 + u, u, psum);
+        const int dn = int (tp[8 * (u + 56)]) - int (tp[8 * (u + 56) + 4]), dold = int (tp[8 * u]) - int (tp[8 * u + 4]);
+        psum += uint32_t (dn < 0 ? -dn : dn) - uint32_t (dold < 0 ? -dold : dold);
       }
-      if (it == 0) start_phase = __builtin_amdgcn_readfirstlane (best);
-      if (t < kD8Win) w.match[t] = int (w.c[(t + 56) * 8 + start_phase] - w.c[t * 8 + start_phase]);
+    } else {
+      auto absd = [&] (int row) -> uint32_t { const int d = dval (5 * 8 + 8 * row + col); return uint32_t (d < 0 ? -d : d); };
+      uint32_t psum = 0;
+      for (int r = 0; r < 56; r++) psum += absd (t0 + r);
+      for (int u = 0; u < 21; u++) {
+        step_out (t0 + u, u, psum);
+        if (u + 1 < 21) psum += absd (t0 + u + 56) - absd (t0 + u);
+      }
     }
     __builtin_amdgcn_s_waitcnt (0xc07f);
     __builtin_amdgcn_wave_barrier ();
@@ -497,6 +509,20 @@ void d8_tail_kernel (const D8Params q, int32_t *dnext)
       d -= mag_of_V<CONV> (q.sp.iq, CONV == kConvMagU16 ? q.sp.navail : q.sp.nsamples, q.sp.halo, q.sp.ov, q.sp.block_samples, q.sp.lut256, (long long) P + 4);
   }
   dnext[idx] = d;
+}
+
+// addresses the ICAO cache holds when the run starts: they can match an address/parity message from the first step on
+__global__ void d8_seed_kernel (uint32_t *announce, const uint32_t *addr, uint32_t n)
+{
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) atomicOr (&announce[addr[i] >> 5], 1u << (addr[i] & 31));
+}
+
+hipError_t launch_d8_seed (uint32_t *announce, const uint32_t *addr, uint32_t n, hipStream_t stream)
+{
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL (d8_seed_kernel, dim3 ((n + 255) / 256), dim3 (256), 0, stream, announce, addr, n);
+  return hipGetLastError ();
 }
 
 // index just behind the last step that needs the running average (0 = none)
