@@ -45,27 +45,8 @@ __device__ __forceinline__ int dprime_tile (const D8Params &q, const uint16_t *t
   return v;
 }
 
-// column-wise exclusive prefix sums of c[rows][8] in place, rows = 8 * per; total goes to row `rows`
-__device__ __forceinline__ void column_prefix (uint32_t *c, uint32_t *tot, int per, int lane)
-{
-  const int i = lane & 7, seg = lane >> 3;
-  uint32_t run = 0;
-  for (int r = seg * per; r < seg * per + per; r++) { const uint32_t v = c[r * 8 + i]; c[r * 8 + i] = run; run += v; }
-  tot[lane] = run;
-  __builtin_amdgcn_s_waitcnt (0xc07f);
-  __builtin_amdgcn_wave_barrier ();
-  uint32_t offset = 0;
-  for (int s = 0; s < seg; s++) offset += tot[s * 8 + i];
-  for (int r = seg * per; r < seg * per + per; r++) c[r * 8 + i] += offset;
-  if (seg == 7) c[8 * per * 8 + i] = offset + run;
-  __builtin_amdgcn_s_waitcnt (0xc07f);
-  __builtin_amdgcn_wave_barrier ();
-}
-
 struct TrigLds {
   uint16_t tile[kTrigTile];
-  uint32_t c[(kTrigRows + 1) * 8];
-  uint32_t tot[64];
   uint16_t lut[256];
 };
 
@@ -133,40 +114,50 @@ void d8_trig_kernel (const D8Params q, uint64_t strip_limit)
   const long long Plo = g0 - kD8LookAhead, Phi = Plo + kTrigRows * 8;
   bool plain = Plo >= 0 && uint64_t (Phi) + 4 < q.T;
   if (plain && q.bshift < 63) plain = (uint64_t (Plo) >> q.bshift) == ((uint64_t (Phi) + 4) >> q.bshift);
+
+  // Lane = segment * 8 + column: eight segments of 32 steps slide their own 56-row window sum (ref: :235-271), the
+  // eight sums of a step sit in eight neighbouring lanes.
+  static_assert (kD8StripSteps == 256, "eight segments of 32 steps");
+  const int col = lane & 7, seg = lane >> 3, t0 = seg * 32;
+  uint32_t on_bits = 0, am_bits = 0;
+  auto step_out = [&] (int u, uint32_t psum) {
+    uint32_t mxv = psum;
+    mxv = max (mxv, dpp_mov<0xB1> (mxv));                // quad_perm [1,0,3,2]
+    mxv = max (mxv, dpp_mov<0x4E> (mxv));                // quad_perm [2,3,0,1]
+    mxv = max (mxv, dpp_mov<0x141> (mxv));               // row_half_mirror: the other quad of the eight
+    const long long n = n0 + t0 + u;
+    const bool valid = uint64_t (n) < q.nsteps;
+    if (valid && mxv > uint32_t (kD8Ambig)) on_bits |= 1u << u;
+    if (valid && mxv > 0 && mxv <= uint32_t (kD8Ambig)) am_bits |= 1u << u;
+    if (q.write_arrays && valid && col == 0) { q.p0[n] = psum; q.mx[n] = mxv; }
+  };
   if (plain) {
-    const uint16_t *t = w.tile + int (Plo - x0);
-    for (int idx = lane; idx < kTrigRows * 8; idx += 64) {
-      const int d = int (t[idx]) - int (t[idx + 4]);
-      w.c[idx] = uint32_t (d < 0 ? -d : d);
+    const uint16_t *tp = w.tile + int (Plo - x0) + col + 8 * t0;             // row r of this lane's segment: tp[8 r], tp[8 r + 4]
+    uint32_t psum = 0;
+#pragma unroll 8
+    for (int r = 0; r < 56; r++) { const int d = int (tp[8 * r]) - int (tp[8 * r + 4]); psum += uint32_t (d < 0 ? -d : d); }
+#pragma unroll 8
+    for (int u = 0; u < 32; u++) {
+      step_out (u, psum);
+      const int dn = int (tp[8 * (u + 56)]) - int (tp[8 * (u + 56) + 4]), dold = int (tp[8 * u]) - int (tp[8 * u + 4]);
+      psum += uint32_t (dn < 0 ? -dn : dn) - uint32_t (dold < 0 ? -dold : dold);
     }
   } else {
-    for (int idx = lane; idx < kTrigRows * 8; idx += 64) {
-      const int d = dprime_tile (q, w.tile, x0, g0 + idx);
-      w.c[idx] = uint32_t (d < 0 ? -d : d);
+    auto absd = [&] (int row) -> uint32_t { const int d = dprime_tile (q, w.tile, x0, g0 + 8 * row + col); return uint32_t (d < 0 ? -d : d); };
+    uint32_t psum = 0;
+    for (int r = 0; r < 56; r++) psum += absd (t0 + r);
+    for (int u = 0; u < 32; u++) {
+      step_out (u, psum);
+      if (u + 1 < 32) psum += absd (t0 + u + 56) - absd (t0 + u);
     }
   }
-  __builtin_amdgcn_s_waitcnt (0xc07f);
-  __builtin_amdgcn_wave_barrier ();
-  column_prefix (w.c, w.tot, kTrigRows / 8, lane);
-
-  uint32_t namb = 0;
-#pragma unroll
-  for (int it = 0; it < kD8StripSteps / 64; it++) {
-    const int s = it * 64 + lane;
-    const long long n = n0 + s;
-    const uint4 a0 = *reinterpret_cast<const uint4 *> (&w.c[s * 8]), a1 = *reinterpret_cast<const uint4 *> (&w.c[s * 8 + 4]);
-    const uint4 b0 = *reinterpret_cast<const uint4 *> (&w.c[(s + 56) * 8]), b1 = *reinterpret_cast<const uint4 *> (&w.c[(s + 56) * 8 + 4]);
-    const uint32_t ph0 = b0.x - a0.x;
-    uint32_t mxv = max (max (max (ph0, b0.y - a0.y), max (b0.z - a0.z, b0.w - a0.w)),
-                        max (max (b1.x - a1.x, b1.y - a1.y), max (b1.z - a1.z, b1.w - a1.w)));
-    const bool valid = uint64_t (n) < q.nsteps;
-    const bool on = valid && mxv > uint32_t (kD8Ambig);
-    const bool am = valid && mxv > 0 && mxv <= uint32_t (kD8Ambig);
-    const u64 bon = __ballot (on), bam = __ballot (am);
-    if (lane == 0) { q.trig[(n0 >> 6) + it] = bon; q.amb[(n0 >> 6) + it] = bam; }
-    if (q.write_arrays && valid) { q.p0[n] = ph0; q.mx[n] = mxv; }
-    namb += __popcll (bam);
+  // word (n0 >> 6) + seg / 2 of the bit arrays, half seg & 1: every lane of a segment holds the same 32 bits
+  if (col == 0) {
+    reinterpret_cast<uint32_t *> (q.trig)[(n0 >> 5) + seg] = on_bits;
+    reinterpret_cast<uint32_t *> (q.amb)[(n0 >> 5) + seg] = am_bits;
   }
+  uint32_t namb = col == 0 ? uint32_t (__popc (am_bits)) : 0u;
+  for (int d = 32; d >= 1; d >>= 1) namb += uint32_t (__shfl_xor (int (namb), d, 64));
   if (lane == 0 && namb) atomicAdd (q.amb_count, namb);
 }
 
