@@ -257,40 +257,7 @@ void accept_pass_2000 (const Record *rec, const uint64_t *pos, size_t n, uint32_
 void accept_pass_8000 (const D8Window *win, size_t nwin, const Record *rec, uint32_t B, int bshift, uint64_t T, uint32_t ov,
                        uint64_t first_sample, uint32_t sample_rate, const Pass8000Hooks &hooks, Pass8000Stats &st)
 {
-  for (size_t wi = 0; wi < nwin; wi++) {
-    const D8Window &w = win[wi];
-    const Record *r0 = rec + w.pad;
-    int best = -1; uint32_t besti = 0;
-    for (uint32_t k = 0; k < w.nrec; k++) {                        // ref: :368-379, `if (message_result > best_result)`
-      const int sc = hooks.score (r0[k], (r0[k].phase >> 4) ? kLongBits : kShortBits);
-      if (sc > best) { best = sc; besti = k; }
-    }
-    if (best < 0) continue;
-    st.valid_preamble++; st.demodulated++;                         // ref: :412, 424
-    const Record &r = r0[besti];
-    const int pass = r.phase >> 4, shift = r.phase & 15, nbytes = pass ? kLongBytes : kShortBytes;
-    const int64_t position_g = (pass ? w.g_long : w.g_short) + int64_t (nbytes + 1) * 64 + 8 * shift;   // ref: :376
-    const uint64_t done = uint64_t (8 * (w.s + kD8Win - 1));
-    const uint64_t blkc = bshift >= 63 ? 0 : done >> bshift;      // the block whose call completes the window
-    const int position = int (position_g - int64_t (blkc * B));
-    const int slen = len_by_type (r.df) * 8;
-    const uint64_t counter = first_sample + blkc * B;
-    const uint64_t block_ts = uint64_t ((double (counter) * 12E6) / double (sample_rate));   // ref: src/infile.c:143
-    const uint64_t ts = block_ts + uint64_t (int64_t ((position - kD8LookAhead - slen - int (ov)) * 12 / 8));   // ref: :421-422
-    modes_message mm;
-    memset (&mm, 0, sizeof mm);
-    const int rc = hooks.decode (r, ts, &mm);
-    if (rc < 0) { st.CRC_bad++; if (rc == -1) st.rejected_unknown++; continue; }
-    if (mm.error_bits == 1) st.CRC_single_bit_fix++; else if (mm.error_bits == 2) st.CRC_two_bits_fix++; else st.CRC_good++;
-    mm.timestamp = ts;
-    mm.score = int16_t (best);
-    mm.block = uint32_t (first_sample / B + blkc);
-    mm.j = uint32_t (position);
-    int m_start = position - kD8LookAhead - slen;                  // ref: :469-484
-    const uint64_t mlen_c = std::min<uint64_t> (B, T - blkc * B);
-    if (!(m_start >= 0 && uint64_t (m_start + slen) <= mlen_c)) m_start = -1;
-    hooks.emit (mm, r, blkc, m_start, slen);
-  }
+  accept_pass_8000_with (win, nwin, rec, B, bshift, T, ov, first_sample, sample_rate, hooks.score, hooks.decode, hooks.emit, st);
 }
 
 void accept_pass_2400ac (const Record *rec, const uint64_t *pos, size_t n, uint32_t B, uint64_t first_sample,

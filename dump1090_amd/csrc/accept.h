@@ -4,6 +4,7 @@
 // scan kernel left.  Works on pre-digested records (syndrome + table hit already known).
 #pragma once
 #include <stdint.h>
+#include <cstring>
 #include <functional>
 #include <vector>
 #include "common.h"
@@ -89,5 +90,51 @@ struct Pass8000Hooks {
 };
 void accept_pass_8000 (const D8Window *win, size_t nwin, const Record *rec, uint32_t block_samples, int bshift, uint64_t T,
                        uint32_t ov, uint64_t first_sample, uint32_t sample_rate, const Pass8000Hooks &hooks, Pass8000Stats &st);
+
+// The same walk with the three hooks as plain callables (the bulk engine inlines its own rules here; the function above
+// wraps the bound host callbacks of the drop-in entry point).
+template <class Score, class Decode, class Emit>
+inline void accept_pass_8000_with (const D8Window *win, size_t nwin, const Record *rec, uint32_t B, int bshift, uint64_t T, uint32_t ov,
+                                   uint64_t first_sample, uint32_t sample_rate, Score &&score, Decode &&decode, Emit &&emit, Pass8000Stats &st)
+{
+  uint64_t ts_blk = ~0ull, block_ts = 0;                           // block_ts of the block seen last (it changes every 64 K samples)
+  for (size_t wi = 0; wi < nwin; wi++) {
+    const D8Window &w = win[wi];
+    const Record *r0 = rec + w.pad;
+    int best = -1; uint32_t besti = 0;
+    for (uint32_t k = 0; k < w.nrec; k++) {                        // ref: :368-379, `if (message_result > best_result)`
+      const int sc = score (r0[k], (r0[k].phase >> 4) ? kLongBits : kShortBits);
+      if (sc > best) { best = sc; besti = k; }
+    }
+    if (best < 0) continue;
+    st.valid_preamble++; st.demodulated++;                         // ref: :412, 424
+    const Record &r = r0[besti];
+    const int pass = r.phase >> 4, shift = r.phase & 15, nbytes = pass ? kLongBytes : kShortBytes;
+    const int64_t position_g = (pass ? w.g_long : w.g_short) + int64_t (nbytes + 1) * 64 + 8 * shift;   // ref: :376
+    const uint64_t done = uint64_t (8 * (w.s + kD8Win - 1));
+    const uint64_t blkc = bshift >= 63 ? 0 : done >> bshift;      // the block whose call completes the window
+    const int position = int (position_g - int64_t (blkc * B));
+    const int slen = len_by_type (r.df) * 8;
+    if (blkc != ts_blk) {
+      const uint64_t counter = first_sample + blkc * B;
+      block_ts = uint64_t ((double (counter) * 12E6) / double (sample_rate));   // ref: src/infile.c:143
+      ts_blk = blkc;
+    }
+    const uint64_t ts = block_ts + uint64_t (int64_t ((position - kD8LookAhead - slen - int (ov)) * 12 / 8));   // ref: :421-422
+    modes_message mm;
+    memset (&mm, 0, sizeof mm);
+    const int rc = decode (r, ts, &mm);
+    if (rc < 0) { st.CRC_bad++; if (rc == -1) st.rejected_unknown++; continue; }
+    if (mm.error_bits == 1) st.CRC_single_bit_fix++; else if (mm.error_bits == 2) st.CRC_two_bits_fix++; else st.CRC_good++;
+    mm.timestamp = ts;
+    mm.score = int16_t (best);
+    mm.block = uint32_t (first_sample / B + blkc);
+    mm.j = uint32_t (position);
+    int m_start = position - kD8LookAhead - slen;                  // ref: :469-484
+    const uint64_t mlen_c = B < T - blkc * B ? uint64_t (B) : T - blkc * B;
+    if (!(m_start >= 0 && uint64_t (m_start + slen) <= mlen_c)) m_start = -1;
+    emit (mm, r, blkc, m_start, slen);
+  }
+}
 
 }  // namespace modes

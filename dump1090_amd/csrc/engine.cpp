@@ -914,18 +914,17 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
 
   Pass8000Stats ps;
   std::vector<uint64_t> rpos; std::vector<uint32_t> rlen, rmsg;
-  Pass8000Hooks hooks;
-  hooks.score = [&] (const Record &r, int) { return score_record (r, e->cache); };
-  hooks.decode = [&] (const Record &r, uint64_t, modes_message *out) { return accept_record (r, e->cache, out); };
-  hooks.emit = [&] (modes_message &m, const Record &, uint64_t blkc, int m_start, int slen) {
-    if (!m.addr) return;                                          // ref: src/demod-8000.c:487
-    if (m_start >= 0) { rpos.push_back (blkc * B + uint64_t (m_start)); rlen.push_back (uint32_t (slen)); rmsg.push_back (uint32_t (e->messages.size ())); }
-    e->messages.push_back (m);
-  };
   rpos.reserve (nwin); rlen.reserve (nwin); rmsg.reserve (nwin);
   e->messages.reserve (nwin);
   const auto t_host0 = std::chrono::steady_clock::now ();
-  accept_pass_8000 (wins, nwin, recs, B, q.bshift, T, e->ov, first_sample, e->cfg.sample_rate, hooks, ps);
+  accept_pass_8000_with (wins, nwin, recs, B, q.bshift, T, e->ov, first_sample, e->cfg.sample_rate,
+    [&] (const Record &r, int) { return score_record (r, e->cache); },
+    [&] (const Record &r, uint64_t, modes_message *out) { return accept_record (r, e->cache, out); },
+    [&] (modes_message &m, const Record &, uint64_t blkc, int m_start, int slen) {
+      if (!m.addr) return;                                          // ref: src/demod-8000.c:487
+      if (m_start >= 0) { rpos.push_back (blkc * B + uint64_t (m_start)); rlen.push_back (uint32_t (slen)); rmsg.push_back (uint32_t (e->messages.size ())); }
+      e->messages.push_back (m);
+    }, ps);
   if (getenv ("MODES_TIMING")) fprintf (stderr, "run_8000: ordered pass over %zu windows / %zu records: %.3f ms, %zu messages\n", size_t (nwin), size_t (nrec), std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - t_host0).count (), e->messages.size ());
   e->stats.valid_preamble = ps.valid_preamble; e->stats.demodulated = ps.demodulated;
   e->stats.CRC_good = ps.CRC_good; e->stats.CRC_bad = ps.CRC_bad; e->stats.CRC_single_bit_fix = ps.CRC_single_bit_fix;
