@@ -159,6 +159,18 @@ def run_workload(name, args, world, rank, local, dev, want_cpu):
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kernel,
                 "kernel_ms": round(kernel_ms, 4), "alg_bytes_per_sample": alg_bps}
+    if kernel == "scan2400_kernel" and not dc and nrec == 1:
+        # what binds the scan kernel is VALU issue, not HBM: instruction counts per strip from the committed
+        # PMC pass (profiles/README.md) priced at 4 cycles per wave64 instruction and 1024 SIMDs at 2.4 GHz
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_scan_stages.json")) as f:
+                pm = json.load(f)[fmt]["per_strip"]["through_stage_D"]
+            floor_ms = pm["INSTS_VALU"] * 4 * (nsamples / 2048 / 1024) / 2.4e9 * 1e3
+            roofline["valu_issue"] = {"insts_per_2048_positions": pm["INSTS_VALU"], "floor_ms": round(floor_ms, 4),
+                                      "frac_of_kernel_ms": round(floor_ms / kernel_ms, 3) if kernel_ms > 0 else None,
+                                      "source": "profiles/r01_pmc_scan_stages.json"}
+        except (OSError, KeyError):
+            pass
     if k2:
         roofline["second_kernel"] = {"kernel": "scan2400_kernel" if dc else "d8_trig_kernel", "kernel_ms": round(k2 / args.steps / nrec, 4)}
     if dc:
