@@ -283,8 +283,11 @@ void d8_chain_walk_kernel (const D8Params q, const long long *pre, long long *pe
 // ---------------------------------------------------------------------------------------------
 // one completed window per wave (ref: :331-420): match curve, peak, the two search strings, 32 candidates
 // ---------------------------------------------------------------------------------------------
+#ifndef D8WIN_WAVES
+#define D8WIN_WAVES 4
+#endif
 template <int CONV>
-__global__ __launch_bounds__ (64 * kW8)
+__global__ __launch_bounds__ (64 * kW8) __attribute__ ((amdgpu_waves_per_eu (D8WIN_WAVES, D8WIN_WAVES)))
 void d8_window_kernel (const D8Params q)
 {
   __shared__ WinLds lds[kW8];
