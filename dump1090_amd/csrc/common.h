@@ -170,6 +170,7 @@ struct D8Params {
   D8Window       *windows;       // [nchunks][kD8WinCap]
   Record         *records;       // [nchunks][kD8WinCap][kD8Cand]
   uint32_t        nchunks;
+  uint32_t        chunk0;        // first chunk of the launch: window / count / gather kernels run on chunk ranges
   uint32_t       *announce;      // [2^24 / 32] addresses that can enter the ICAO cache during the run, or null = no filter
 };
 

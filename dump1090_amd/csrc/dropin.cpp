@@ -650,9 +650,9 @@ static bool demod_8000_locked (const mag_buf *mag, uint32_t block)
   HIP_OK (launch_d8_trig (q, 0, nullptr));
   HIP_OK (launch_d8_acc (q, nsteps, d_acc, nullptr));           // the running average is carried to the next call: always formed
   HIP_OK (launch_d8_chain (q, s.trig_tail, 0ll, d_pre, d_pending, nullptr));
-  HIP_OK (launch_d8_windows (q, nullptr));
+  HIP_OK (launch_d8_windows (q, q.nchunks, nullptr));
   HIP_OK (launch_d8_tail (q, s.dnext, nullptr));
-  HIP_OK (launch_d8_count (q, s.chunk_rec, nullptr));
+  HIP_OK (launch_d8_count (q, q.nchunks, s.chunk_rec, nullptr));
   std::vector<uint32_t> wc (nchunks), rcnt (2 * size_t (nchunks));
   std::vector<uint64_t> trig (words);
   long long small[8];
@@ -686,7 +686,7 @@ static bool demod_8000_locked (const mag_buf *mag, uint32_t block)
   }
   if (!nwin) return true;
   HIP_OK (hipMemcpyAsync (s.off, off.data (), off.size () * sizeof (uint64_t), hipMemcpyHostToDevice, nullptr));
-  HIP_OK (launch_d8_gather (q, s.off, s.off + nchunks + 1, s.win_packed, s.rec_packed, nullptr));
+  HIP_OK (launch_d8_gather (q, q.nchunks, s.off, s.off + nchunks + 1, s.win_packed, s.rec_packed, nullptr));
   std::vector<D8Window> wins (nwin);
   std::vector<Record> recs (nrec + 1);
   HIP_OK (hipMemcpyAsync (wins.data (), s.win_packed, nwin * sizeof (D8Window), hipMemcpyDeviceToHost, nullptr));

@@ -167,6 +167,8 @@ struct modes_engine {
   PinBuf<D8Window> pin_wins;
   PinBuf<Record> pin_recs;
   PinBuf<uint32_t> pin_bits;                  // announce bitmap as the run starts with it
+  PinBuf<uint32_t> pin_counts;                // per-chunk window / record counts
+  std::vector<hipEvent_t> d8_events;          // three per range of chunks: windows begin / end, counts (then records) on the host
   unsigned long long *d_stats = nullptr;
   uint32_t cap = 0;
   // float converters with the DC block on (kernels_dc.hip): V = [overlap | magnitudes] of the shard in HBM
@@ -565,7 +567,8 @@ void modes_engine_destroy (modes_engine *e)
   e->d8_win_count.release (); e->d8_chunk_rec.release (); e->d8_announce.release (); e->d8_table.release (); e->d8_entry.release ();
   e->d8_win_start.release (); e->d8_small.release (); e->d8_windows.release (); e->d8_win_packed.release ();
   e->d8_records.release (); e->d8_rec_packed.release ();
-  e->pin_wins.release (); e->pin_recs.release (); e->pin_bits.release ();
+  e->pin_wins.release (); e->pin_recs.release (); e->pin_bits.release (); e->pin_counts.release ();
+  for (hipEvent_t ev : e->d8_events) if (ev) (void) hipEventDestroy (ev);
   if (e->tabs.short_tab) (void) hipFree (e->tabs.short_tab);
   if (e->tabs.long_tab) (void) hipFree (e->tabs.long_tab);
   if (e->tabs.lut256) (void) hipFree (e->tabs.lut256);
@@ -881,51 +884,81 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
     }
   }
   HIP_TRY (launch_d8_chain (q, 0ull, 0ll, d_pre, d_pending, stream));
-  HIP_TRY (hipEventRecord (e->ev[0], stream));
-  HIP_TRY (launch_d8_windows (q, stream));
-  HIP_TRY (hipEventRecord (e->ev[1], stream));
-  HIP_TRY (launch_d8_count (q, e->d8_chunk_rec.p, stream));
-  std::vector<uint32_t> wc (nchunks), rcnt (2 * size_t (nchunks));
-  HIP_TRY (hipMemcpyAsync (wc.data (), e->d8_win_count.p, nchunks * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
-  HIP_TRY (hipMemcpyAsync (rcnt.data (), e->d8_chunk_rec.p, 2 * size_t (nchunks) * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
-  HIP_TRY (hipStreamSynchronize (stream));
-  (void) hipEventElapsedTime (&e->kernel_ms[0], e->ev[0], e->ev[1]);
-  (void) hipEventElapsedTime (&e->kernel_ms[1], e->ev[2], e->ev[3]);
-  std::vector<uint64_t> off (2 * size_t (nchunks) + 2);
-  uint64_t nwin = 0, nrec = 0;
-  for (uint32_t c = 0; c < nchunks; c++) {
-    if (wc[c] > uint32_t (kD8WinCap)) return fail (MODES_E_OVERFLOW, "chunk %u holds %u windows (cap %d)", c, wc[c], kD8WinCap);
-    off[c] = nwin; off[nchunks + 1 + c] = nrec;
-    nwin += rcnt[nchunks + c]; nrec += rcnt[c];                    // windows and records that survive the address filter
+  // The completed windows in up to four ranges of chunks.  While the host walks one range's records in order (the
+  // part of demod_8000 that needs the live ICAO cache), the device works on the next range: the queue is
+  //   windows(0) count(0) | gather(0) copy(0) windows(1) count(1) | gather(1) copy(1) windows(2) ...
+  // A record of range r can only be accepted through an address announced in ranges <= r (or cached at the start), and
+  // count(r) runs behind windows(r), so the address filter sees all it needs.
+  const uint32_t nranges = nchunks >= 16 ? 4u : 1u;
+  if (e->d8_events.size () < 3 * size_t (nranges)) {
+    const size_t have = e->d8_events.size ();
+    e->d8_events.resize (3 * size_t (nranges), nullptr);
+    for (size_t i = have; i < e->d8_events.size (); i++) HIP_TRY (hipEventCreate (&e->d8_events[i]));
   }
-  e->stats.candidates = nrec;
-  if (!nwin) return MODES_OK;
-  if ((rc = e->d8_win_packed.reserve (nwin)) != MODES_OK) return rc;
-  if ((rc = e->d8_rec_packed.reserve (nrec + 1)) != MODES_OK) return rc;
-  HIP_TRY (hipMemcpyAsync (e->d8_off.p, off.data (), off.size () * sizeof (uint64_t), hipMemcpyHostToDevice, stream));
-  HIP_TRY (launch_d8_gather (q, e->d8_off.p, e->d8_off.p + nchunks + 1, e->d8_win_packed.p, e->d8_rec_packed.p, stream));
-  if ((rc = e->pin_wins.reserve (nwin)) != MODES_OK) return rc;
-  if ((rc = e->pin_recs.reserve (nrec + 1)) != MODES_OK) return rc;
-  const D8Window *wins = e->pin_wins.p;
-  const Record *recs = e->pin_recs.p;
-  HIP_TRY (hipMemcpyAsync (e->pin_wins.p, e->d8_win_packed.p, nwin * sizeof (D8Window), hipMemcpyDeviceToHost, stream));
-  if (nrec) HIP_TRY (hipMemcpyAsync (e->pin_recs.p, e->d8_rec_packed.p, nrec * sizeof (Record), hipMemcpyDeviceToHost, stream));
-  HIP_TRY (hipStreamSynchronize (stream));
-
+  if ((rc = e->pin_counts.reserve (3 * size_t (nchunks))) != MODES_OK) return rc;
+  uint32_t *wc = e->pin_counts.p, *rcnt = e->pin_counts.p + nchunks;           // rcnt: [records per chunk | live windows per chunk]
+  auto range_lo = [&] (uint32_t r) { return uint32_t (uint64_t (nchunks) * r / nranges); };
+  auto queue_windows = [&] (uint32_t r) -> int {
+    const uint32_t c0 = range_lo (r), n = range_lo (r + 1) - c0;
+    q.chunk0 = c0;
+    HIP_TRY (hipEventRecord (e->d8_events[3 * r], stream));
+    HIP_TRY (launch_d8_windows (q, n, stream));
+    HIP_TRY (hipEventRecord (e->d8_events[3 * r + 1], stream));
+    HIP_TRY (launch_d8_count (q, n, e->d8_chunk_rec.p, stream));
+    HIP_TRY (hipMemcpyAsync (wc + c0, e->d8_win_count.p + c0, n * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY (hipMemcpyAsync (rcnt + c0, e->d8_chunk_rec.p + c0, n * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY (hipMemcpyAsync (rcnt + nchunks + c0, e->d8_chunk_rec.p + nchunks + c0, n * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY (hipEventRecord (e->d8_events[3 * r + 2], stream));
+    return MODES_OK;
+  };
   Pass8000Stats ps;
   std::vector<uint64_t> rpos; std::vector<uint32_t> rlen, rmsg;
-  rpos.reserve (nwin); rlen.reserve (nwin); rmsg.reserve (nwin);
-  e->messages.reserve (nwin);
-  const auto t_host0 = std::chrono::steady_clock::now ();
-  accept_pass_8000_with (wins, nwin, recs, B, q.bshift, T, e->ov, first_sample, e->cfg.sample_rate,
-    [&] (const Record &r, int) { return score_record (r, e->cache); },
-    [&] (const Record &r, uint64_t, modes_message *out) { return accept_record (r, e->cache, out); },
-    [&] (modes_message &m, const Record &, uint64_t blkc, int m_start, int slen) {
-      if (!m.addr) return;                                          // ref: src/demod-8000.c:487
-      if (m_start >= 0) { rpos.push_back (blkc * B + uint64_t (m_start)); rlen.push_back (uint32_t (slen)); rmsg.push_back (uint32_t (e->messages.size ())); }
-      e->messages.push_back (m);
-    }, ps);
-  if (getenv ("MODES_TIMING")) fprintf (stderr, "run_8000: ordered pass over %zu windows / %zu records: %.3f ms, %zu messages\n", size_t (nwin), size_t (nrec), std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - t_host0).count (), e->messages.size ());
+  std::vector<uint64_t> off (2 * size_t (nchunks) + 2);
+  double host_ms = 0.0;
+  e->kernel_ms[0] = 0;
+  if ((rc = queue_windows (0)) != MODES_OK) return rc;
+  for (uint32_t r = 0; r < nranges; r++) {
+    const uint32_t c0 = range_lo (r), c1 = range_lo (r + 1);
+    HIP_TRY (hipEventSynchronize (e->d8_events[3 * r + 2]));
+    if (r == 0) (void) hipEventElapsedTime (&e->kernel_ms[1], e->ev[2], e->ev[3]);
+    uint64_t nwin = 0, nrec = 0;
+    for (uint32_t c = c0; c < c1; c++) {
+      if (wc[c] > uint32_t (kD8WinCap)) return fail (MODES_E_OVERFLOW, "chunk %u holds %u windows (cap %d)", c, wc[c], kD8WinCap);
+      off[c] = nwin; off[nchunks + 1 + c] = nrec;
+      nwin += rcnt[nchunks + c]; nrec += rcnt[c];                  // windows and records that survive the address filter
+    }
+    e->stats.candidates += nrec;
+    if (nwin) {
+      if ((rc = e->d8_win_packed.reserve (nwin)) != MODES_OK) return rc;
+      if ((rc = e->d8_rec_packed.reserve (nrec + 1)) != MODES_OK) return rc;
+      if ((rc = e->pin_wins.reserve (nwin)) != MODES_OK) return rc;
+      if ((rc = e->pin_recs.reserve (nrec + 1)) != MODES_OK) return rc;
+      HIP_TRY (hipMemcpyAsync (e->d8_off.p + c0, off.data () + c0, (c1 - c0) * sizeof (uint64_t), hipMemcpyHostToDevice, stream));
+      HIP_TRY (hipMemcpyAsync (e->d8_off.p + nchunks + 1 + c0, off.data () + nchunks + 1 + c0, (c1 - c0) * sizeof (uint64_t), hipMemcpyHostToDevice, stream));
+      q.chunk0 = c0;
+      HIP_TRY (launch_d8_gather (q, c1 - c0, e->d8_off.p, e->d8_off.p + nchunks + 1, e->d8_win_packed.p, e->d8_rec_packed.p, stream));
+      HIP_TRY (hipMemcpyAsync (e->pin_wins.p, e->d8_win_packed.p, nwin * sizeof (D8Window), hipMemcpyDeviceToHost, stream));
+      if (nrec) HIP_TRY (hipMemcpyAsync (e->pin_recs.p, e->d8_rec_packed.p, nrec * sizeof (Record), hipMemcpyDeviceToHost, stream));
+      HIP_TRY (hipEventRecord (e->d8_events[3 * r + 2], stream));
+    }
+    if (r + 1 < nranges && (rc = queue_windows (r + 1)) != MODES_OK) return rc;     // the device's work while the host walks range r
+    float wms = 0;
+    (void) hipEventElapsedTime (&wms, e->d8_events[3 * r], e->d8_events[3 * r + 1]);
+    e->kernel_ms[0] += wms;
+    if (!nwin) continue;
+    HIP_TRY (hipEventSynchronize (e->d8_events[3 * r + 2]));
+    const auto t_host0 = std::chrono::steady_clock::now ();
+    accept_pass_8000_with (e->pin_wins.p, nwin, e->pin_recs.p, B, q.bshift, T, e->ov, first_sample, e->cfg.sample_rate,
+      [&] (const Record &rr, int) { return score_record (rr, e->cache); },
+      [&] (const Record &rr, uint64_t, modes_message *out) { return accept_record (rr, e->cache, out); },
+      [&] (modes_message &m, const Record &, uint64_t blkc, int m_start, int slen) {
+        if (!m.addr) return;                                        // ref: src/demod-8000.c:487
+        if (m_start >= 0) { rpos.push_back (blkc * B + uint64_t (m_start)); rlen.push_back (uint32_t (slen)); rmsg.push_back (uint32_t (e->messages.size ())); }
+        e->messages.push_back (m);
+      }, ps);
+    host_ms += std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - t_host0).count ();
+  }
+  if (getenv ("MODES_TIMING")) fprintf (stderr, "run_8000: ordered pass %.3f ms in %u ranges, %zu messages\n", host_ms, nranges, e->messages.size ());
   e->stats.valid_preamble = ps.valid_preamble; e->stats.demodulated = ps.demodulated;
   e->stats.CRC_good = ps.CRC_good; e->stats.CRC_bad = ps.CRC_bad; e->stats.CRC_single_bit_fix = ps.CRC_single_bit_fix;
   e->stats.CRC_two_bits_fix = ps.CRC_two_bits_fix; e->stats.CRC_fixed = ps.CRC_single_bit_fix + ps.CRC_two_bits_fix;

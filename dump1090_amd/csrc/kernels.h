@@ -22,11 +22,11 @@ hipError_t launch_d8_acc (const D8Params &q, uint64_t limit, int32_t *acc_out, h
 hipError_t launch_d8_last_amb (const uint64_t *amb, uint64_t nwords, unsigned long long *limit, hipStream_t stream);
 hipError_t launch_d8_chain (const D8Params &q, unsigned long long trig_tail, long long search0, long long *pre,
                             long long *pending_out, hipStream_t stream);
-hipError_t launch_d8_windows (const D8Params &q, hipStream_t stream);
+hipError_t launch_d8_windows (const D8Params &q, uint32_t nch, hipStream_t stream);   // chunks q.chunk0 .. + nch
 hipError_t launch_d8_tail (const D8Params &q, int32_t *dnext, hipStream_t stream);
 hipError_t launch_d8_seed (uint32_t *announce, const uint32_t *addr, uint32_t n, hipStream_t stream);
-hipError_t launch_d8_count (const D8Params &q, uint32_t *chunk_rec, hipStream_t stream);
-hipError_t launch_d8_gather (const D8Params &q, const uint64_t *win_off, const uint64_t *rec_off, D8Window *win_out,
+hipError_t launch_d8_count (const D8Params &q, uint32_t nch, uint32_t *chunk_rec, hipStream_t stream);
+hipError_t launch_d8_gather (const D8Params &q, uint32_t nch, const uint64_t *win_off, const uint64_t *rec_off, D8Window *win_out,
                              Record *rec_out, hipStream_t stream);
 hipError_t launch_convert (int conv, const uint8_t *iq, uint16_t *mag, size_t n, const uint16_t *lut256,
                            unsigned long long *power_u64, hipStream_t stream);

@@ -297,7 +297,7 @@ void d8_window_kernel (const D8Params q)
   WinLds &w = lds[wv];
   crc_tab[threadIdx.x & 255] = q.sp.crc_table[threadIdx.x & 255];
   __syncthreads ();
-  const uint32_t chunk = blockIdx.x;
+  const uint32_t chunk = q.chunk0 + blockIdx.x;
   const uint32_t nwin = min (q.win_count[chunk], uint32_t (kD8WinCap));
   for (int i = lane; i < 256; i += 64) w.lut[i] = q.sp.lut256 ? q.sp.lut256[i] : uint16_t (0);
 
@@ -555,13 +555,14 @@ __global__ __launch_bounds__ (256)
 void d8_count_kernel (const D8Params q, uint32_t *chunk_rec)
 {
   __shared__ uint32_t part[256];
-  const uint32_t c = blockIdx.x, nwin = min (q.win_count[c], uint32_t (kD8WinCap));
+  const uint32_t c = q.chunk0 + blockIdx.x, nwin = min (q.win_count[c], uint32_t (kD8WinCap));
   uint32_t sum = 0;
   for (uint32_t k = threadIdx.x; k < nwin; k += 256) {
     D8Window &h = q.windows[size_t (c) * kD8WinCap + k];
-    const Record *src = q.records + (size_t (c) * kD8WinCap + k) * kD8Cand;
+    Record *src = q.records + (size_t (c) * kD8WinCap + k) * kD8Cand;
     uint32_t live = 0;
-    for (uint32_t r = 0; r < h.nrec; r++) live += record_relevant (src[r], q.announce);
+    // the verdict is kept in the record: the gather must see what was counted, whatever later windows announce meanwhile
+    for (uint32_t r = 0; r < h.nrec; r++) { const bool rel = record_relevant (src[r], q.announce); src[r].flags = rel; live += rel; }
     h.pad = live;                                              // records that survive the filter
     sum += live;
   }
@@ -583,7 +584,7 @@ __global__ __launch_bounds__ (256)
 void d8_gather_kernel (const D8Params q, const uint64_t *win_off, const uint64_t *rec_off, D8Window *win_out, Record *rec_out)
 {
   __shared__ uint32_t pre[kD8WinCap + 1], wpre[kD8WinCap + 1];
-  const uint32_t c = blockIdx.x, nwin = min (q.win_count[c], uint32_t (kD8WinCap));
+  const uint32_t c = q.chunk0 + blockIdx.x, nwin = min (q.win_count[c], uint32_t (kD8WinCap));
   if (threadIdx.x == 0) {
     uint32_t run = 0, wrun = 0;
     for (uint32_t k = 0; k < nwin; k++) {
@@ -599,7 +600,7 @@ void d8_gather_kernel (const D8Params q, const uint64_t *win_off, const uint64_t
     const Record *src = q.records + (size_t (c) * kD8WinCap + k) * kD8Cand;
     uint32_t n = 0;
     for (uint32_t r = 0; r < h.nrec; r++)
-      if (record_relevant (src[r], q.announce)) {
+      if (src[r].flags) {
         const uint4 *s4 = reinterpret_cast<const uint4 *> (src + r);
         uint4 *d4 = reinterpret_cast<uint4 *> (rec_out + ro + n);
         d4[0] = s4[0]; d4[1] = s4[1];
@@ -611,16 +612,16 @@ void d8_gather_kernel (const D8Params q, const uint64_t *win_off, const uint64_t
   }
 }
 
-hipError_t launch_d8_count (const D8Params &q, uint32_t *chunk_rec, hipStream_t stream)
+hipError_t launch_d8_count (const D8Params &q, uint32_t nch, uint32_t *chunk_rec, hipStream_t stream)
 {
-  if (q.nchunks) hipLaunchKernelGGL (d8_count_kernel, dim3 (q.nchunks), dim3 (256), 0, stream, q, chunk_rec);
+  if (nch) hipLaunchKernelGGL (d8_count_kernel, dim3 (nch), dim3 (256), 0, stream, q, chunk_rec);
   return hipGetLastError ();
 }
 
-hipError_t launch_d8_gather (const D8Params &q, const uint64_t *win_off, const uint64_t *rec_off, D8Window *win_out,
+hipError_t launch_d8_gather (const D8Params &q, uint32_t nch, const uint64_t *win_off, const uint64_t *rec_off, D8Window *win_out,
                              Record *rec_out, hipStream_t stream)
 {
-  if (q.nchunks) hipLaunchKernelGGL (d8_gather_kernel, dim3 (q.nchunks), dim3 (256), 0, stream, q, win_off, rec_off, win_out, rec_out);
+  if (nch) hipLaunchKernelGGL (d8_gather_kernel, dim3 (nch), dim3 (256), 0, stream, q, win_off, rec_off, win_out, rec_out);
   return hipGetLastError ();
 }
 
@@ -666,10 +667,10 @@ hipError_t launch_d8_chain (const D8Params &q, unsigned long long trig_tail, lon
   return hipGetLastError ();
 }
 
-hipError_t launch_d8_windows (const D8Params &q, hipStream_t stream)
+hipError_t launch_d8_windows (const D8Params &q, uint32_t nch, hipStream_t stream)
 {
-  if (q.nchunks == 0) return hipSuccess;
-  const dim3 grid (q.nchunks, 16), block (64 * kW8);
+  if (nch == 0) return hipSuccess;
+  const dim3 grid (nch, 16), block (64 * kW8);
   D8_DISPATCH (d8_window_kernel, grid, block, q);
   return hipGetLastError ();
 }

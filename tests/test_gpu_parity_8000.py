@@ -70,3 +70,22 @@ def test_messages_straddling_block_boundaries():
         x[p:p + len(env)] += 0.3 * np.exp(2j * np.pi * rng.random()) * env
     iq = synth.quantise(x, "sc16")
     check(iq, "sc16", len(offs) - 3)
+
+
+def test_long_recording_runs_in_chunk_ranges():
+    """Sixteen chunks and more (8.4 M samples) make the engine walk the windows in four ranges, each range's ordered
+    pass on the host overlapping the next range's kernels: the message list must not notice the seams."""
+    import torch
+    from dump1090_amd import synth_torch
+    n = 17 * 65536 * 8 + 12345
+    d, _ = synth_torch.capture_gpu(n, 8.0e6, "sc16", seed=91, frames_per_sec=2500, device="cuda:0", n_icao=8, n_bank=512)
+    torch.cuda.synchronize()
+    iq = d.cpu().numpy().view(np.int16)
+    exp, est = oracle_run(iq, "sc16", rate=8000000, fix_bits=1)
+    e = da.Engine(8000000, da.INPUT_SC16, fix_bits=1)
+    e.run_device(d.data_ptr(), d.numel() * d.element_size())
+    got, gst = e.messages(), e.stats()
+    assert len(exp) > 1000
+    assert_same_messages(got, exp)
+    for k in STAT_KEYS:
+        assert gst[k] == est[k], (k, gst[k], est[k])
