@@ -231,24 +231,38 @@ void d8_chain_table_kernel (const D8Params q)
 // One thread: what happens before step 0 (a window carried in, triggers among the last steps of the previous
 // call, ref: :493-496 re-scans them), then the entry offset of every chunk.
 // pre[0] = count, pre[1..2] = window starts (< 0) found there.
-__global__ void d8_chain_resolve_kernel (const D8Params q, u64 trig_tail, long long search0, long long *pre)
+// The chain through the chunks is one dependent table look-up per chunk: the workgroup stages 256 chunks' tables in LDS
+// at a time, thread 0 follows them there.
+__global__ __launch_bounds__ (256)
+void d8_chain_resolve_kernel (const D8Params q, u64 trig_tail, long long search0, long long *pre)
 {
-  if (threadIdx.x || blockIdx.x) return;
-  long long pos = search0;
-  int npre = 0;
-  if (q.pending < 0) { pre[1 + npre++] = q.pending; pos = q.pending + kD8Net; }
-  while (pos < 0) {                                        // steps -64 .. -1 of the previous call
-    const int b = int (pos + 64);
-    const u64 word = b >= 0 ? trig_tail & (~0ull << b) : trig_tail;
-    if (!word) { pos = 0; break; }
-    const long long s = (long long) __builtin_ctzll (word) - 64;
-    pre[1 + npre++] = s;
-    pos = s + kD8Net;
+  __shared__ __attribute__ ((aligned (16))) uint8_t tab[256 * 128];
+  uint32_t e = 0;
+  if (threadIdx.x == 0) {
+    long long pos = search0;
+    int npre = 0;
+    if (q.pending < 0) { pre[1 + npre++] = q.pending; pos = q.pending + kD8Net; }
+    while (pos < 0) {                                        // steps -64 .. -1 of the previous call
+      const int b = int (pos + 64);
+      const u64 word = b >= 0 ? trig_tail & (~0ull << b) : trig_tail;
+      if (!word) { pos = 0; break; }
+      const long long s = (long long) __builtin_ctzll (word) - 64;
+      pre[1 + npre++] = s;
+      pos = s + kD8Net;
+    }
+    pre[0] = npre;
+    e = uint32_t (min (pos, (long long) (kD8Net - 1)));
+    q.entry[0] = uint8_t (e);
   }
-  pre[0] = npre;
-  uint32_t e = uint32_t (min (pos, (long long) (kD8Net - 1)));
-  q.entry[0] = uint8_t (e);
-  for (uint32_t c = 0; c < q.nchunks; c++) { e = q.table[size_t (c) * 128 + e]; q.entry[c + 1] = uint8_t (e); }
+  for (uint32_t base = 0; base < q.nchunks; base += 256) {
+    const uint32_t n = min (256u, q.nchunks - base);
+    const uint4 *src = reinterpret_cast<const uint4 *> (q.table + size_t (base) * 128);
+    for (uint32_t i = threadIdx.x; i < n * 8; i += 256) reinterpret_cast<uint4 *> (tab)[i] = src[i];
+    __syncthreads ();
+    if (threadIdx.x == 0)
+      for (uint32_t c = 0; c < n; c++) { e = tab[c * 128 + e]; q.entry[base + c + 1] = uint8_t (e); }
+    __syncthreads ();
+  }
 }
 
 // per chunk: the window openings themselves; the last one may still be open when the stream ends
@@ -662,7 +676,7 @@ hipError_t launch_d8_chain (const D8Params &q, unsigned long long trig_tail, lon
                             long long *pending_out, hipStream_t stream)
 {
   if (q.nchunks) hipLaunchKernelGGL (d8_chain_table_kernel, dim3 (q.nchunks), dim3 (128), 0, stream, q);
-  hipLaunchKernelGGL (d8_chain_resolve_kernel, dim3 (1), dim3 (1), 0, stream, q, (u64) trig_tail, search0, pre);
+  hipLaunchKernelGGL (d8_chain_resolve_kernel, dim3 (1), dim3 (256), 0, stream, q, (u64) trig_tail, search0, pre);
   if (q.nchunks) hipLaunchKernelGGL (d8_chain_walk_kernel, dim3 (q.nchunks), dim3 (64), 0, stream, q, pre, pending_out);
   return hipGetLastError ();
 }
