@@ -4,7 +4,8 @@ import csv, glob, json, os, collections
 raw, out = "gpurun_out/profiles_raw", "profiles"
 os.makedirs(out, exist_ok=True)
 for old in glob.glob(out + "/r01_*"):
-    os.remove(old)
+    if "pmc_scan_stages" not in old:                 # written by tools/stage_pmc_json.py
+        os.remove(old)
 for d in sorted(glob.glob(raw + "/stats_*")):
     wl = os.path.basename(d)[6:]
     f = glob.glob(d + "/*/*kernel_stats.csv")[0]
