@@ -696,7 +696,7 @@ void accept_kernel (const AcceptParams p)
     const uint32_t incl = uint32_t (wave_incl_scan (int (c), lane));
     w.prefix[lane] = incl - c;
     w.accn[lane] = 0;
-    total = uint32_t (__shfl (int (incl), 63, 64));
+    total = uint32_t (__builtin_amdgcn_readlane (int (incl), 63));
   }
   __builtin_amdgcn_s_waitcnt (0xc07f);
   __builtin_amdgcn_wave_barrier ();

@@ -388,7 +388,7 @@ void scan2000_kernel (const ScanParams p)
   // ---- queue 1 ----
   const int mycnt = __popcll (any);
   const int incl = wave_incl_scan (mycnt, lane);
-  const int n1 = __shfl (incl, 63, 64);
+  const int n1 = __builtin_amdgcn_readlane (incl, 63);          // scalar: the loops below branch on the scalar unit
   if (n1 > kQ1Cap) overflow = true;
   if (!overflow) {
     int slot = incl - mycnt;
@@ -425,9 +425,9 @@ void scan2000_kernel (const ScanParams p)
     const u64 both = vpm | mam;
     const int c = __popcll (both);
     const int inc = wave_incl_scan (c, lane);
-    n2 = __shfl (inc, 63, 64);
+    n2 = __builtin_amdgcn_readlane (inc, 63);
     nvp = uint32_t (wave_incl_scan (__popcll (vpm), lane));
-    nvp = uint32_t (__shfl (int (nvp), 63, 64));
+    nvp = uint32_t (__builtin_amdgcn_readlane (int (nvp), 63));
     if (n2 > kQ2Cap2000) overflow = true;
     if (!overflow) {
       int slot = inc - c;
@@ -513,7 +513,7 @@ void scan2000_kernel (const ScanParams p)
       }
     }
     const int inc = wave_incl_scan (cnt, lane);
-    const uint32_t total = nrec + uint32_t (__shfl (inc, 63, 64));
+    const uint32_t total = nrec + uint32_t (__builtin_amdgcn_readlane (inc, 63));
     if (total > p.cap) { overflow = true; break; }
     if (p.write_records) {
       uint4 *dst = reinterpret_cast<uint4 *> (out + nrec + (inc - cnt));
