@@ -57,6 +57,14 @@ struct WinLds {
   uint16_t lut[256];
 };
 
+// |a - b| + c in one VALU operation (v_sad_u32); the compiler does not form it from the C expression
+__device__ __forceinline__ uint32_t sad_u32 (uint32_t a, uint32_t b, uint32_t c)
+{
+  uint32_t d;
+  asm ("v_sad_u32 %0, %1, %2, %3" : "=v" (d) : "v" (a), "v" (b), "v" (c));
+  return d;
+}
+
 __device__ __forceinline__ int len_by_type8 (int df) { return (df == 16 || df == 17 || df == 19 || df == 20 || df == 21) ? kLongBits : kShortBits; }
 
 __device__ __forceinline__ uint32_t crc_words (const uint32_t *tab, const uint32_t *w, int nbytes)
@@ -135,12 +143,11 @@ void d8_trig_kernel (const D8Params q, uint64_t strip_limit)
     const uint16_t *tp = w.tile + int (Plo - x0) + col + 8 * t0;             // row r of this lane's segment: tp[8 r], tp[8 r + 4]
     uint32_t psum = 0;
 #pragma unroll 8
-    for (int r = 0; r < 56; r++) { const int d = int (tp[8 * r]) - int (tp[8 * r + 4]); psum += uint32_t (d < 0 ? -d : d); }
+    for (int r = 0; r < 56; r++) psum = sad_u32 (tp[8 * r], tp[8 * r + 4], psum);         // v_sad_u32: |a - b| + c in one operation
 #pragma unroll 8
     for (int u = 0; u < 32; u++) {
       step_out (u, psum);
-      const int dn = int (tp[8 * (u + 56)]) - int (tp[8 * (u + 56) + 4]), dold = int (tp[8 * u]) - int (tp[8 * u + 4]);
-      psum += uint32_t (dn < 0 ? -dn : dn) - uint32_t (dold < 0 ? -dold : dold);
+      psum = sad_u32 (tp[8 * (u + 56)], tp[8 * (u + 56) + 4], psum) - sad_u32 (tp[8 * u], tp[8 * u + 4], 0u);
     }
   } else {
     auto absd = [&] (int row) -> uint32_t { const int d = dprime_tile (q, w.tile, x0, g0 + 8 * row + col); return uint32_t (d < 0 ? -d : d); };
@@ -377,12 +384,11 @@ void d8_window_kernel (const D8Params q)
       const uint16_t *tp = w.tile + tbase + 5 * 8 + col + 8 * t0;            // row r of this lane's segment: tp[8 r], tp[8 r + 4]
       uint32_t psum = 0;
 #pragma unroll 8
-      for (int r = 0; r < 56; r++) { const int d = int (tp[8 * r]) - int (tp[8 * r + 4]); psum += uint32_t (d < 0 ? -d : d); }
+      for (int r = 0; r < 56; r++) psum = sad_u32 (tp[8 * r], tp[8 * r + 4], psum);         // v_sad_u32: |a - b| + c in one operation
 #pragma unroll 7
       for (int u = 0; u < 21; u++) {
         step_out (t0 + u, u, psum);
-        const int dn = int (tp[8 * (u + 56)]) - int (tp[8 * (u + 56) + 4]), dold = int (tp[8 * u]) - int (tp[8 * u + 4]);
-        psum += uint32_t (dn < 0 ? -dn : dn) - uint32_t (dold < 0 ? -dold : dold);
+        psum = sad_u32 (tp[8 * (u + 56)], tp[8 * (u + 56) + 4], psum) - sad_u32 (tp[8 * u], tp[8 * u + 4], 0u);
       }
     } else {
       auto absd = [&] (int row) -> uint32_t { const int d = dval (5 * 8 + 8 * row + col); return uint32_t (d < 0 ? -d : d); };
