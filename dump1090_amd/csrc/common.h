@@ -137,6 +137,7 @@ struct AcceptParams {
   uint32_t       *blk_stats;     // [nblocks][kBlkStats]
   const uint64_t *vp_bitmap;     // may be null
   uint32_t       *changed;       // set to 1 when a delta entry differs from the previous round
+  const uint32_t *dirty;         // [nblocks] 1 = the block's entry cache changed since the round before (null: run every block)
   int32_t         mode;          // 2400 or 2000: which demodulator's loop is replayed
 };
 

@@ -162,6 +162,7 @@ struct modes_engine {
   DevBuf<uint32_t> d8_p0, d8_mx, d8_win_count, d8_chunk_rec, d8_announce;
   DevBuf<uint8_t> d8_table, d8_entry;
   DevBuf<int64_t> d8_win_start, d8_small;
+  DevBuf<uint32_t> dirty;
   DevBuf<D8Window> d8_windows, d8_win_packed;
   DevBuf<Record> d8_records, d8_rec_packed;
   PinBuf<D8Window> pin_wins;
@@ -423,6 +424,7 @@ int run_accept_on_device (modes_engine *e, const ScanParams &sp, uint64_t first_
   if ((rc = e->acc_counts.reserve (sp.nstrips)) != MODES_OK) return rc;
   if ((rc = e->blk_stats.reserve (size_t (nblocks) * kBlkStats)) != MODES_OK) return rc;
   if ((rc = e->small_u32.reserve (2 * kIcaoSlots + 16)) != MODES_OK) return rc;
+  if ((rc = e->dirty.reserve (nblocks)) != MODES_OK) return rc;
   uint32_t *d_cache_in = e->small_u32.p, *d_cache_out = e->small_u32.p + kIcaoSlots, *d_changed = e->small_u32.p + 2 * kIcaoSlots;
 
   HIP_TRY (hipMemcpyAsync (d_cache_in, e->cache.raw (), kIcaoSlots * sizeof (uint32_t), hipMemcpyHostToDevice, stream));
@@ -447,7 +449,9 @@ int run_accept_on_device (modes_engine *e, const ScanParams &sp, uint64_t first_
     HIP_TRY (hipMemsetAsync (d_changed, 0, sizeof (uint32_t), stream));
     HIP_TRY (launch_accept2400 (ap, stream));
     HIP_TRY (hipMemcpyAsync (pin_changed, d_changed, sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY (launch_snapshots (e->delta.p, nblocks, d_cache_in, e->chunk_last.p, e->chunk_entry.p, e->snap_in.p, d_cache_out, stream));
+    HIP_TRY (hipMemsetAsync (e->dirty.p, 0, size_t (nblocks) * sizeof (uint32_t), stream));
+    HIP_TRY (launch_snapshots (e->delta.p, nblocks, d_cache_in, e->chunk_last.p, e->chunk_entry.p, e->snap_in.p, d_cache_out, e->dirty.p, stream));
+    ap.dirty = e->dirty.p;                                      // from the second round on
     // totals of accepted messages and the block statistics, read back together with the scan's totals
     HIP_TRY (launch_count_scan (e->acc_counts.p, e->vp_counts.p, sp.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p, d_totals + 4, stream));
     HIP_TRY (launch_blk_stats_sum (e->blk_stats.p, nblocks, e->d_stats + 8, stream));
@@ -566,7 +570,7 @@ void modes_engine_destroy (modes_engine *e)
   e->d8_trig.release (); e->d8_amb.release (); e->d8_off.release (); e->d8_p0.release (); e->d8_mx.release ();
   e->d8_win_count.release (); e->d8_chunk_rec.release (); e->d8_announce.release (); e->d8_table.release (); e->d8_entry.release ();
   e->d8_win_start.release (); e->d8_small.release (); e->d8_windows.release (); e->d8_win_packed.release ();
-  e->d8_records.release (); e->d8_rec_packed.release ();
+  e->d8_records.release (); e->d8_rec_packed.release (); e->dirty.release ();
   e->pin_wins.release (); e->pin_recs.release (); e->pin_bits.release (); e->pin_counts.release ();
   for (hipEvent_t ev : e->d8_events) if (ev) (void) hipEventDestroy (ev);
   if (e->tabs.short_tab) (void) hipFree (e->tabs.short_tab);

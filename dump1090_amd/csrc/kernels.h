@@ -41,7 +41,7 @@ hipError_t launch_raw_format (const void *msgs, uint32_t n, uint32_t *len, uint6
 hipError_t launch_dc_chain (int conv, const DcParams &p, uint32_t ndesc, hipStream_t stream);
 hipError_t launch_accept2400 (const AcceptParams &p, hipStream_t stream);
 hipError_t launch_snapshots (const uint32_t *delta, uint32_t nblocks, const uint32_t *cache_in, uint32_t *chunk_last,
-                             uint32_t *chunk_entry, uint32_t *snap_in, uint32_t *cache_out, hipStream_t stream);
+                             uint32_t *chunk_entry, uint32_t *snap_in, uint32_t *cache_out, uint32_t *dirty, hipStream_t stream);
 hipError_t launch_snap_broadcast (const uint32_t *cache_in, uint32_t nblocks, uint32_t *snap_in, hipStream_t stream);
 hipError_t launch_emit2400 (const EmitParams &p, hipStream_t stream);
 hipError_t launch_strip_offsets (const uint32_t *acc_counts, uint32_t nstrips, const uint64_t *chunk_sum, uint64_t *offsets, hipStream_t stream);

@@ -674,6 +674,7 @@ void accept_kernel (const AcceptParams p)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t blk = blockIdx.x * 4 + wv;
   if (blk >= p.nblocks) return;
+  if (p.dirty && !p.dirty[blk]) return;                      // same entry cache as in the round before: same results
   AcceptLds &w = lds[wv];
   for (int i = lane; i < int (kIcaoSlots); i += 64) w.cache[i] = p.snap_in[size_t (blk) * kIcaoSlots + i];
   if (lane < int (kIcaoSlots / 32)) w.written[lane] = 0;
@@ -909,14 +910,16 @@ void snap_chunk_scan_kernel (const uint32_t *chunk_last, uint32_t nchunks, const
 }
 
 __global__ __launch_bounds__ (256)
-void snap_fill_kernel (const uint32_t *delta, uint32_t nblocks, const uint32_t *chunk_entry, uint32_t *snap_in)
+void snap_fill_kernel (const uint32_t *delta, uint32_t nblocks, const uint32_t *chunk_entry, uint32_t *snap_in, uint32_t *dirty)
 {
   const uint32_t s = blockIdx.x * 256 + threadIdx.x, chunk = blockIdx.y;
   if (s >= kIcaoSlots) return;
   uint32_t cur = chunk_entry[size_t (chunk) * kIcaoSlots + s];
   const uint32_t b0 = chunk * kSnapChunk, b1 = min (b0 + kSnapChunk, nblocks);
   for (uint32_t b = b0; b < b1; b++) {
-    snap_in[size_t (b) * kIcaoSlots + s] = cur;
+    // a block whose entry cache is what it was in the round before would repeat itself: only the others run again
+    uint32_t *sn = snap_in + size_t (b) * kIcaoSlots + s;
+    if (*sn != cur) { *sn = cur; dirty[b] = 1u; }
     const uint32_t d = delta[size_t (b) * kIcaoSlots + s];
     if (d & kDeltaWritten) cur = d & ~kDeltaWritten;
   }
@@ -1334,13 +1337,13 @@ hipError_t launch_accept2400 (const AcceptParams &p, hipStream_t stream)
 
 // delta -> snap_in for the next round; chunk_last/chunk_entry hold (nblocks/32 + 1) * 1024 words each
 hipError_t launch_snapshots (const uint32_t *delta, uint32_t nblocks, const uint32_t *cache_in, uint32_t *chunk_last,
-                             uint32_t *chunk_entry, uint32_t *snap_in, uint32_t *cache_out, hipStream_t stream)
+                             uint32_t *chunk_entry, uint32_t *snap_in, uint32_t *cache_out, uint32_t *dirty, hipStream_t stream)
 {
   if (nblocks == 0) return hipSuccess;
   const uint32_t nchunks = (nblocks + kSnapChunk - 1) / kSnapChunk;
   hipLaunchKernelGGL (snap_chunk_last_kernel, dim3 (kIcaoSlots / 256, nchunks), dim3 (256), 0, stream, delta, nblocks, chunk_last);
   hipLaunchKernelGGL (snap_chunk_scan_kernel, dim3 (kIcaoSlots / 256), dim3 (256), 0, stream, chunk_last, nchunks, cache_in, chunk_entry, cache_out);
-  hipLaunchKernelGGL (snap_fill_kernel, dim3 (kIcaoSlots / 256, nchunks), dim3 (256), 0, stream, delta, nblocks, chunk_entry, snap_in);
+  hipLaunchKernelGGL (snap_fill_kernel, dim3 (kIcaoSlots / 256, nchunks), dim3 (256), 0, stream, delta, nblocks, chunk_entry, snap_in, dirty);
   return hipGetLastError ();
 }
 
