@@ -199,6 +199,7 @@ struct DcParams {
 struct EmitParams {
   const Record   *records; const uint32_t *counts; const uint32_t *acc_counts; const uint64_t *offsets;     // messages of all earlier strips
   uint32_t        cap, nstrips;
+  uint32_t        strip_begin, strip_end;   // the launch covers these strips (the message list is emitted in parts)
   // stream geometry for timestamps and the signal level
   const uint8_t  *iq; uint64_t nsamples, navail; const uint16_t *halo; uint32_t ov, block_samples; int32_t conv;
   const uint16_t *lut256;

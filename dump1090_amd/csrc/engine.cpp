@@ -163,6 +163,9 @@ struct modes_engine {
   DevBuf<uint8_t> d8_table, d8_entry;
   DevBuf<int64_t> d8_win_start, d8_small;
   DevBuf<uint32_t> dirty;
+  PinBuf<uint64_t> pin_chunks;                // messages in front of every 1024-strip chunk (read back with the totals)
+  hipStream_t copy_stream = nullptr;          // read-back of one part of the message list while the next part is formed
+  std::vector<hipEvent_t> emit_events;
   DevBuf<D8Window> d8_windows, d8_win_packed;
   DevBuf<Record> d8_records, d8_rec_packed;
   PinBuf<D8Window> pin_wins;
@@ -425,6 +428,10 @@ int run_accept_on_device (modes_engine *e, const ScanParams &sp, uint64_t first_
   if ((rc = e->blk_stats.reserve (size_t (nblocks) * kBlkStats)) != MODES_OK) return rc;
   if ((rc = e->small_u32.reserve (2 * kIcaoSlots + 16)) != MODES_OK) return rc;
   if ((rc = e->dirty.reserve (nblocks)) != MODES_OK) return rc;
+  const uint32_t nsc = (sp.nstrips + 1023) / 1024;               // chunks of the strip-count scan
+  if ((rc = e->pin_chunks.reserve (nsc + 1)) != MODES_OK) return rc;
+  uint32_t want_parts = 1;                                        // see the emit step below
+  if (const char *ev = getenv ("MODES_EMIT_PARTS")) { const int v = atoi (ev); if (v >= 1 && uint32_t (v) <= nsc && v <= 16) want_parts = uint32_t (v); }
   uint32_t *d_cache_in = e->small_u32.p, *d_cache_out = e->small_u32.p + kIcaoSlots, *d_changed = e->small_u32.p + 2 * kIcaoSlots;
 
   HIP_TRY (hipMemcpyAsync (d_cache_in, e->cache.raw (), kIcaoSlots * sizeof (uint32_t), hipMemcpyHostToDevice, stream));
@@ -457,6 +464,7 @@ int run_accept_on_device (modes_engine *e, const ScanParams &sp, uint64_t first_
     HIP_TRY (launch_blk_stats_sum (e->blk_stats.p, nblocks, e->d_stats + 8, stream));
     HIP_TRY (hipMemcpyAsync (e->pin_small, d_totals, 32 * sizeof (unsigned long long), hipMemcpyDeviceToHost, stream));
     HIP_TRY (hipMemcpyAsync (e->pin_cache, d_cache_out, kIcaoSlots * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
+    if (want_parts > 1) HIP_TRY (hipMemcpyAsync (e->pin_chunks.p, e->chunk_sum.p, size_t (nsc) * sizeof (uint64_t), hipMemcpyDeviceToHost, stream));
     HIP_TRY (hipStreamSynchronize (stream));
     rounds++;
     if (!*pin_changed) break;
@@ -502,9 +510,33 @@ int run_accept_on_device (modes_engine *e, const ScanParams &sp, uint64_t first_
     ep.messages = e->d_messages.p;
     ep.mode = e->mode;
     HIP_TRY (launch_strip_offsets (e->acc_counts.p, sp.nstrips, e->chunk_sum.p, e->offsets.p, stream));
-    HIP_TRY (launch_emit2400 (ep, stream));
-    HIP_TRY (hipMemcpyAsync (e->pin_msgs, e->d_messages.p, nm * sizeof (modes_message), hipMemcpyDeviceToHost, stream));
+    // The list can be formed in parts (whole 1024-strip chunks, whose first message index the host already holds), one
+    // part travelling to the host on a second stream while the next is formed (MODES_EMIT_PARTS=n).
+    // Off unless asked for: four parts measure 3-5 % faster on 0.4-1.3 M messages, but one run in three loses a
+    // millisecond when the read-back on the second stream takes a slower copy path.
+    const uint32_t parts = want_parts;
+    if (parts > 1) {
+      if (!e->copy_stream) HIP_TRY (hipStreamCreateWithFlags (&e->copy_stream, hipStreamNonBlocking));
+      while (e->emit_events.size () < parts) { hipEvent_t ev; HIP_TRY (hipEventCreateWithFlags (&ev, hipEventDisableTiming)); e->emit_events.push_back (ev); }
+    }
+    const modes_message *d_msgs = static_cast<const modes_message *> (e->d_messages.p);
+    for (uint32_t r = 0; r < parts; r++) {
+      const uint32_t c0 = uint32_t (uint64_t (nsc) * r / parts), c1 = uint32_t (uint64_t (nsc) * (r + 1) / parts);
+      ep.strip_begin = c0 * 1024u;
+      ep.strip_end = c1 * 1024u < sp.nstrips ? c1 * 1024u : sp.nstrips;
+      const size_t m0 = size_t (e->pin_chunks.p[c0]), m1 = c1 < nsc ? size_t (e->pin_chunks.p[c1]) : nm;
+      HIP_TRY (launch_emit2400 (ep, stream));
+      if (m1 <= m0) continue;
+      hipStream_t cs = stream;
+      if (parts > 1) {
+        HIP_TRY (hipEventRecord (e->emit_events[r], stream));
+        HIP_TRY (hipStreamWaitEvent (e->copy_stream, e->emit_events[r], 0));
+        cs = e->copy_stream;
+      }
+      HIP_TRY (hipMemcpyAsync (e->pin_msgs + m0, d_msgs + m0, (m1 - m0) * sizeof (modes_message), hipMemcpyDeviceToHost, cs));
+    }
     HIP_TRY (hipStreamSynchronize (stream));
+    if (parts > 1) HIP_TRY (hipStreamSynchronize (e->copy_stream));
   }
   return MODES_OK;
 }
@@ -570,7 +602,9 @@ void modes_engine_destroy (modes_engine *e)
   e->d8_trig.release (); e->d8_amb.release (); e->d8_off.release (); e->d8_p0.release (); e->d8_mx.release ();
   e->d8_win_count.release (); e->d8_chunk_rec.release (); e->d8_announce.release (); e->d8_table.release (); e->d8_entry.release ();
   e->d8_win_start.release (); e->d8_small.release (); e->d8_windows.release (); e->d8_win_packed.release ();
-  e->d8_records.release (); e->d8_rec_packed.release (); e->dirty.release ();
+  e->d8_records.release (); e->d8_rec_packed.release (); e->dirty.release (); e->pin_chunks.release ();
+  if (e->copy_stream) (void) hipStreamDestroy (e->copy_stream);
+  for (hipEvent_t ev : e->emit_events) if (ev) (void) hipEventDestroy (ev);
   e->pin_wins.release (); e->pin_recs.release (); e->pin_bits.release (); e->pin_counts.release ();
   for (hipEvent_t ev : e->d8_events) if (ev) (void) hipEventDestroy (ev);
   if (e->tabs.short_tab) (void) hipFree (e->tabs.short_tab);

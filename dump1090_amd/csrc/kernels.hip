@@ -1019,10 +1019,10 @@ __global__ __launch_bounds__ (256)
 void emit2400_kernel (const EmitParams p)
 {
   // a wave looks at kEmitStrips strips at once: most hold no accepted message
-  const uint32_t strip_base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * kEmitStrips;
+  const uint32_t strip_base = p.strip_begin + (blockIdx.x * 4 + (threadIdx.x >> 6)) * kEmitStrips;
   const int lane = threadIdx.x & 63;
-  if (strip_base >= p.nstrips) return;
-  const uint32_t cnt = (lane < kEmitStrips && strip_base + lane < p.nstrips) ? p.acc_counts[strip_base + lane] : 0u;
+  if (strip_base >= p.strip_end) return;
+  const uint32_t cnt = (lane < kEmitStrips && strip_base + lane < p.strip_end) ? p.acc_counts[strip_base + lane] : 0u;
   for (u64 sm = __ballot (cnt != 0); sm; sm &= sm - 1) {
   const uint32_t strip = strip_base + uint32_t (__builtin_ctzll (sm));
   const uint32_t nacc = bcast (cnt, __builtin_ctzll (sm));
@@ -1357,8 +1357,9 @@ hipError_t launch_snap_broadcast (const uint32_t *cache_in, uint32_t nblocks, ui
 
 hipError_t launch_emit2400 (const EmitParams &p, hipStream_t stream)
 {
-  if (p.nstrips == 0) return hipSuccess;
-  const dim3 grid ((p.nstrips + 4 * kEmitStrips - 1) / (4 * kEmitStrips)), block (256);
+  if (p.strip_end <= p.strip_begin) return hipSuccess;
+  const uint32_t n = p.strip_end - p.strip_begin;
+  const dim3 grid ((n + 4 * kEmitStrips - 1) / (4 * kEmitStrips)), block (256);
   switch (p.conv) {
     case kConvUc8Lut: case kConvUc8LutPower: hipLaunchKernelGGL (emit2400_kernel<kConvUc8Lut>, grid, block, 0, stream, p); break;
     case kConvUc8Generic:     hipLaunchKernelGGL (emit2400_kernel<kConvUc8Generic>, grid, block, 0, stream, p); break;
