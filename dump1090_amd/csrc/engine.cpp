@@ -524,7 +524,7 @@ int run_accept_on_device (modes_engine *e, const ScanParams &sp, uint64_t first_
       const uint32_t c0 = uint32_t (uint64_t (nsc) * r / parts), c1 = uint32_t (uint64_t (nsc) * (r + 1) / parts);
       ep.strip_begin = c0 * 1024u;
       ep.strip_end = c1 * 1024u < sp.nstrips ? c1 * 1024u : sp.nstrips;
-      const size_t m0 = size_t (e->pin_chunks.p[c0]), m1 = c1 < nsc ? size_t (e->pin_chunks.p[c1]) : nm;
+      const size_t m0 = (parts > 1 && c0) ? size_t (e->pin_chunks.p[c0]) : 0, m1 = (parts > 1 && c1 < nsc) ? size_t (e->pin_chunks.p[c1]) : nm;
       HIP_TRY (launch_emit2400 (ep, stream));
       if (m1 <= m0) continue;
       hipStream_t cs = stream;
