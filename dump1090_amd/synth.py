@@ -93,11 +93,47 @@ def quantise(x: np.ndarray, fmt: str) -> np.ndarray:
     raise ValueError(fmt)
 
 
-def capture(nsamples: int, sample_rate: float = 2.4e6, fmt: str = "uc8", seed: int = 1, frames_per_sec: float = 1000.0,
-            n_icao: int = 16, noise_sigma: float = 0.01, overlap_fraction: float = 0.1, bitflip1: float = 0.0,
-            bitflip2: float = 0.0, dc_offset: complex = 0.0, ap_fraction: float = 0.0, min_amp_db: float = -32.0,
-            max_amp_db: float = -4.0):
+def capture(nsamples: int, sample_rate: float = 2.4e6, fmt: str = "uc8", seed: int = 1, **kw):
     """Returns (iq array, list of injected frames as dicts {start, msg (as sent), clean (before bit flips), amp})."""
+    x, frames = capture_complex(nsamples, sample_rate, seed, **kw)
+    return quantise(x, fmt), frames
+
+
+# ---- byte streams for the uc8 converters AS WRITTEN (ref: src/convert.c:19-40, SURVEY.md 0.4) ----------------------
+# convert_uc8_nodc_nopower / _power read ONE byte per output sample: out[i] = mag_lut[byte i] for the first `nsamples`
+# bytes of each 256 KiB block, with mag_lut[b] = 360 * b for b <= 128.  A byte stream whose image under that table is
+# a Mode S frame train is therefore: byte = round(envelope magnitude / 360) in the first half of every block.
+LUT_BLOCK_SAMPLES = 131072           # uc8: 256 KiB / 2 bytes per sample
+LUT_STEP = 360                       # mag_lut[b] = 360 * b, b in 0..128
+
+
+def lut_image_bytes(mag_bytes: np.ndarray, seed: int = 0) -> np.ndarray:
+    """mag_bytes[i] (0..128) = the byte the as-written converter must read for output sample i.  Returns the uc8
+    "IQ" buffer (2 bytes per sample) that puts them where the converter looks: the first half of each block; the
+    second half, which the converter never reads, is filled with random bytes."""
+    n = len(mag_bytes)
+    B = LUT_BLOCK_SAMPLES
+    rng = np.random.default_rng(seed)
+    out = rng.integers(0, 256, size=2 * n, dtype=np.uint8)
+    for b0 in range(0, n, B):
+        cnt = min(B, n - b0)
+        out[2 * b0: 2 * b0 + cnt] = mag_bytes[b0: b0 + cnt]
+    return out
+
+
+def capture_lut_image(nsamples: int, sample_rate: float = 2.4e6, seed: int = 1, **kw):
+    """A uc8 buffer whose image under the as-written byte table is the envelope of capture_complex()'s signal
+    (full scale 1.0 -> byte 128 -> magnitude 46080).  Returns (uint8[2 * nsamples], frames)."""
+    x, frames = capture_complex(nsamples, sample_rate, seed, **kw)
+    mb = np.clip(np.round(np.abs(x) * 128.0), 0, 128).astype(np.uint8)
+    return lut_image_bytes(mb, seed), frames
+
+
+def capture_complex(nsamples: int, sample_rate: float = 2.4e6, seed: int = 1, frames_per_sec: float = 1000.0,
+                    n_icao: int = 16, noise_sigma: float = 0.01, overlap_fraction: float = 0.1, bitflip1: float = 0.0,
+                    bitflip2: float = 0.0, dc_offset: complex = 0.0, ap_fraction: float = 0.0, min_amp_db: float = -32.0,
+                    max_amp_db: float = -4.0):
+    """Complex baseband (full scale 1.0) and the list of injected frames."""
     rng = np.random.default_rng(seed)
     x = (rng.standard_normal(nsamples) + 1j * rng.standard_normal(nsamples)) * noise_sigma + dc_offset
     icaos = rng.integers(0x400000, 0x4FFFFF, size=n_icao)
@@ -133,4 +169,4 @@ def capture(nsamples: int, sample_rate: float = 2.4e6, fmt: str = "uc8", seed: i
         else:
             step = len(env) + gap + int(rng.exponential(max(mean_step - len(env) - gap, 1.0)))
         pos += step
-    return quantise(x, fmt), frames
+    return x, frames

@@ -28,7 +28,10 @@ def _bank(rng, sample_rate, n_bank, n_icao, df17_fraction):
 def capture_gpu(nsamples, sample_rate=2.4e6, fmt="uc8", seed=1, frames_per_sec=1000.0, device="cuda:0",
                 noise_sigma=0.01, n_icao=64, n_bank=4096, overlap_fraction=0.1, df17_fraction=0.6,
                 min_amp_db=-32.0, max_amp_db=-4.0, dc_offset=(0.0, 0.0), chunk=1 << 24):
-    """Returns (iq tensor on `device`: uint8[2n] or int16[2n], dict with frame positions / bank indices)."""
+    """Returns (iq tensor on `device`: uint8[2n] or int16[2n], dict with frame positions / bank indices).
+    fmt "uc8lut": a uc8 buffer whose image under the reference's as-written byte table is the signal's envelope
+    (synth.capture_lut_image): byte = round(|x| * 128) in the first half of every 256 KiB block, random bytes in the
+    half the converter never reads."""
     rng = np.random.default_rng(seed)
     bank, msgs = _bank(rng, sample_rate, n_bank, n_icao, df17_fraction)
     L = bank.shape[1]
@@ -52,7 +55,11 @@ def capture_gpu(nsamples, sample_rate=2.4e6, fmt="uc8", seed=1, frames_per_sec=1
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
     bank_t = torch.from_numpy(bank).to(dev)
-    out = torch.empty(2 * nsamples, dtype=torch.uint8 if fmt == "uc8" else torch.int16, device=dev)
+    out = torch.empty(2 * nsamples, dtype=torch.uint8 if fmt in ("uc8", "uc8lut") else torch.int16, device=dev)
+    if fmt == "uc8lut":
+        B = synth.LUT_BLOCK_SAMPLES
+        assert chunk % B == 0
+        out.random_(0, 256, generator=gen)
     ar = torch.arange(L, device=dev)
     for c0 in range(0, nsamples, chunk):
         c1 = min(c0 + chunk, nsamples)
@@ -73,6 +80,15 @@ def capture_gpu(nsamples, sample_rate=2.4e6, fmt="uc8", seed=1, frames_per_sec=1
             idx = idx.clamp(0, n + L - 1)
             x[0].index_put_((idx[ok],), (env * torch.cos(ph)[:, None])[ok], accumulate=True)
             x[1].index_put_((idx[ok],), (env * torch.sin(ph)[:, None])[ok], accumulate=True)
+        if fmt == "uc8lut":
+            mb = torch.clamp(torch.round(torch.sqrt(x[0, :n] ** 2 + x[1, :n] ** 2) * 128.0), 0, 128).to(torch.uint8)
+            nfull = n // B
+            if nfull:
+                out[2 * c0: 2 * (c0 + nfull * B)].view(nfull, 2, B)[:, 0, :] = mb[: nfull * B].view(nfull, B)
+            if n > nfull * B:
+                out[2 * (c0 + nfull * B): 2 * (c0 + nfull * B) + (n - nfull * B)] = mb[nfull * B:]
+            del x, mb
+            continue
         iq = x[:, :n].t().contiguous().view(-1)                  # interleave I,Q
         if fmt == "uc8":
             q = torch.clamp(torch.round(iq * 127.5 + 127.5), 0, 255).to(torch.uint8)

@@ -72,6 +72,46 @@ def test_uc8_lut_as_written_matches_oracle(modes1):
     assert gst["valid_preamble"] == est["valid_preamble"] == 2016
 
 
+@pytest.mark.parametrize("compute_power", [False, True])
+def test_uc8_lut_image_messages_match_oracle(compute_power):
+    """The headline instantiation (scan2400_kernel<kConvUc8Lut>: convert_uc8_nodc_nopower / _power AS WRITTEN, one
+    byte per output sample, ref: src/convert.c:19-40) on an input it decodes: a byte stream whose image under the
+    256-entry table is a frame train (synth.capture_lut_image), eight blocks, frames across every block seam --
+    which for this converter is also the jump over the never-read second half of the block."""
+    iq, frames = synth.capture_lut_image(131072 * 8 + 7001, 2.4e6, seed=41, frames_per_sec=4500, min_amp_db=-22,
+                                         bitflip1=0.2, ap_fraction=0.2)
+    exp, est = oracle_run(iq, "uc8", fix_bits=1, compute_power=compute_power)
+    got, gst = engine_run(iq, "uc8", fix_bits=1, compute_power=compute_power)
+    assert len(exp) > 1000
+    assert_same_messages(got, exp)
+    for k in ("valid_preamble", "demodulated", "CRC_good", "CRC_bad", "CRC_single_bit_fix", "out_of_phase", "demod_rejected_unknown"):
+        assert gst[k] == est[k], k
+    # ground truth of the generator, not only the oracle: most injected frames come back with their bytes
+    sent = {f["clean"] for f in frames}
+    back = sum(1 for g in got if bytes(g["msg"][: int(g["msg_bits"]) // 8]) in sent)
+    assert back > 0.7 * len(frames)
+
+
+def test_uc8_lut_image_frames_on_block_seams():
+    """Frames placed around every 131072-sample block edge of the as-written uc8 converter's output."""
+    rng = np.random.default_rng(43)
+    offs = (-330, -300, -268, -200, -135, -100, -20, -1, 0, 1, 40)
+    B = synth.LUT_BLOCK_SAMPLES
+    n = B * (len(offs) + 1) + 1000
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.01
+    for b, d in enumerate(offs, start=1):
+        for q, make in ((0, synth.make_df17), (-600, synth.make_df17)):
+            msg = make(0x4840D6 + b, bytes(rng.integers(0, 256, 7, dtype=np.uint8)))
+            env = synth.envelope(msg, 2.4e6, rng.random())
+            p = b * B + d + q
+            x[p:p + len(env)] += 0.4 * env
+    iq = synth.lut_image_bytes(np.clip(np.round(np.abs(x) * 128.0), 0, 128).astype(np.uint8), 43)
+    exp, _ = oracle_run(iq, "uc8")
+    got, _ = engine_run(iq, "uc8")
+    assert len(exp) >= 2 * len(offs) - 2
+    assert_same_messages(got, exp)
+
+
 def test_sc16_generic_power_path_matches_oracle():
     """compute_power selects convert_sc16_generic (float path, DC block off)."""
     iq, _ = synth.capture(800_000, 2.4e6, "sc16", seed=5, frames_per_sec=1500)
