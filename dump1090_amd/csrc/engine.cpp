@@ -1193,39 +1193,77 @@ int modes_engine_halo_at (modes_engine *e, const void *d_iq, size_t nbytes, uint
   return MODES_OK;
 }
 
+// Stand-alone converter on device buffers.  The tables and the scratch of this call are kept per device; calls are
+// serialised by a mutex (the scratch is shared), each call waits for its results.
+namespace {
+struct ConvDev {
+  bool ready = false;
+  uint16_t *d_lut = nullptr;
+  unsigned long long *d_power = nullptr;
+  float *d_small = nullptr;                   // [0..1] z_final, [2] power
+  float *d_f[3] = { nullptr, nullptr, nullptr };
+  size_t f_cap = 0;
+};
+constexpr int kMaxConvDevices = 64;
+std::mutex g_conv_mu;
+ConvDev g_conv[kMaxConvDevices];
+}  // namespace
+
 int modes_convert_device (int conv, const void *d_iq, uint16_t *d_mag, size_t nsamples, convert_state *state,
                           double *out_power, void *stream_v)
 {
-  (void) state;
   hipStream_t stream = static_cast<hipStream_t> (stream_v);
   if (conv < 0 || conv > 5) return fail (MODES_E_ARG, "converter id %d", conv);
-  static uint16_t *d_lut = nullptr;
-  static unsigned long long *d_power = nullptr;
-  static bool consts = false;
-  if (!d_lut) {
+  if ((!d_iq || !d_mag) && nsamples) return fail (MODES_E_ARG, "null argument");
+  int dev = 0;
+  HIP_TRY (hipGetDevice (&dev));
+  if (dev < 0 || dev >= kMaxConvDevices) return fail (MODES_E_ARG, "device %d", dev);
+  std::lock_guard<std::mutex> lk (g_conv_mu);
+  ConvDev &c = g_conv[dev];
+  if (!c.ready) {
     uint16_t lut[256];
     build_uc8_byte_lut (lut);
-    HIP_TRY (hipMalloc (reinterpret_cast<void **> (&d_lut), sizeof lut));
-    HIP_TRY (hipMemcpy (d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
-    HIP_TRY (hipMalloc (reinterpret_cast<void **> (&d_power), sizeof (unsigned long long)));
-  }
-  if (!consts) {
+    if (!c.d_lut) HIP_TRY (hipMalloc (reinterpret_cast<void **> (&c.d_lut), sizeof lut));
+    HIP_TRY (hipMemcpy (c.d_lut, lut, sizeof lut, hipMemcpyHostToDevice));
+    if (!c.d_power) HIP_TRY (hipMalloc (reinterpret_cast<void **> (&c.d_power), sizeof (unsigned long long)));
+    if (!c.d_small) HIP_TRY (hipMalloc (reinterpret_cast<void **> (&c.d_small), 4 * sizeof (float)));
     CrcTables t;
     float uc8f[256];
     build_uc8_float_lut (uc8f);
-    HIP_TRY (upload_constants (t.single_bit (), uc8f));
-    consts = true;
+    HIP_TRY (upload_constants (t.single_bit (), uc8f));       // __constant__ tables of the device that is current
+    c.ready = true;
   }
-  if (state && (state->DC_A != 0.0f || state->DC_B != 1.0f) && conv != kConvUc8Lut && conv != kConvUc8LutPower && conv != kConvSc16Int)
-    return fail (MODES_E_ARG, "DC-filter converters are not built yet");
-  HIP_TRY (hipMemsetAsync (d_power, 0, sizeof (unsigned long long), stream));
-  HIP_TRY (launch_convert (conv, static_cast<const uint8_t *> (d_iq), d_mag, nsamples, d_lut, d_power, stream));
-  if (out_power) {
+  if (out_power) *out_power = 0.0;
+  if (nsamples == 0) return MODES_OK;
+  const bool is_float = conv == kConvUc8Generic || conv == kConvSc16Generic || conv == kConvSc16Q11Generic;
+  if (!is_float) {                            // ref: src/convert.c:13-110,247-292 (stateless; state is not touched)
+    HIP_TRY (hipMemsetAsync (c.d_power, 0, sizeof (unsigned long long), stream));
+    HIP_TRY (launch_convert (conv, static_cast<const uint8_t *> (d_iq), d_mag, nsamples, c.d_lut, c.d_power, stream));
     unsigned long long pw = 0;
-    HIP_TRY (hipMemcpyAsync (&pw, d_power, sizeof pw, hipMemcpyDeviceToHost, stream));
+    HIP_TRY (hipMemcpyAsync (&pw, c.d_power, sizeof pw, hipMemcpyDeviceToHost, stream));
     HIP_TRY (hipStreamSynchronize (stream));
-    *out_power = conv == kConvUc8LutPower ? double (pw) / 65535.0 / 65535.0 : 0.0;
+    if (out_power) *out_power = conv == kConvUc8LutPower ? double (pw) / 65535.0 / 65535.0 : 0.0;
+    return MODES_OK;
   }
+  // float converters (ref: src/convert.c:112-245): DC block state in and out through `state` (NULL = DC block off)
+  const float A = state ? state->DC_A : 0.0f, B = state ? state->DC_B : 1.0f;
+  const bool dc = !(A == 0.0f && B == 1.0f);
+  if (!dc && state && (state->z1_I != 0.0f || state->z1_Q != 0.0f))
+    return fail (MODES_E_ARG, "DC block off with a non-zero filter state: convert_init() never produces that");
+  if (nsamples > c.f_cap) {
+    for (float *&p : c.d_f) { if (p) (void) hipFree (p); p = nullptr; }
+    c.f_cap = 0;
+    for (float *&p : c.d_f) HIP_TRY (hipMalloc (reinterpret_cast<void **> (&p), (nsamples + 64) * sizeof (float)));
+    c.f_cap = nsamples;
+  }
+  HIP_TRY (launch_convert_float (conv, static_cast<const uint8_t *> (d_iq), d_mag, nsamples, A, B, state ? state->z1_I : 0.0f,
+                                 state ? state->z1_Q : 0.0f, c.d_f[0], c.d_f[1], c.d_f[2], c.d_small,
+                                 out_power ? c.d_small + 2 : nullptr, stream));
+  float small[3] = { 0, 0, 0 };
+  HIP_TRY (hipMemcpyAsync (small, c.d_small, sizeof small, hipMemcpyDeviceToHost, stream));
+  HIP_TRY (hipStreamSynchronize (stream));
+  if (dc && state) { state->z1_I = small[0]; state->z1_Q = small[1]; }
+  if (out_power) *out_power = double (small[2]);
   return MODES_OK;
 }
 
