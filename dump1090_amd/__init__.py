@@ -141,6 +141,8 @@ def lib():
         L.modes_engine_read_dc_magnitudes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
         L.modes_convert_device.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(ConvertState),
                                            C.POINTER(C.c_double), C.c_void_p]
+        L.modes_convert_device_noalloc.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float,
+                                                   C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         L.modes_hip_bind.argtypes = [C.c_void_p]
         L.convert_init.restype = C.c_void_p
         L.convert_init.argtypes = [C.c_int, C.c_double, C.c_bool, C.c_bool, C.POINTER(C.POINTER(ConvertState))]
@@ -288,6 +290,18 @@ def convert_device(conv_id, d_iq_ptr, d_mag_ptr, nsamples, state=None, want_powe
                                       C.byref(state) if state is not None else None,
                                       C.byref(p) if want_power else None, C.c_void_p(stream) if stream else None))
     return p.value
+
+
+NOALLOC_MAX_SAMPLES = 262144
+CONVERT_RESULT_DTYPE = np.dtype([("out_power", "<f8"), ("z1_I", "<f4"), ("z1_Q", "<f4")])
+
+
+def convert_device_noalloc(conv_id, d_iq_ptr, d_mag_ptr, nsamples, DC_A=0.0, DC_B=1.0, z1_I=0.0, z1_Q=0.0,
+                           d_result_ptr=None, stream=None):
+    """modes_convert_device_noalloc(): allocates nothing, waits for nothing; results land in device memory."""
+    _check(lib().modes_convert_device_noalloc(conv_id, C.c_void_p(d_iq_ptr), C.c_void_p(d_mag_ptr), nsamples, DC_A, DC_B,
+                                              z1_I, z1_Q, C.c_void_p(d_result_ptr) if d_result_ptr else None,
+                                              C.c_void_p(stream) if stream else None))
 
 
 def msg_hex(rec):

@@ -279,6 +279,27 @@ int  modes_convert_device (int converter_id /* row of converters_table, ref: src
                            const void *d_iq, uint16_t *d_mag, size_t nsamples,
                            convert_state *state, double *out_power, void *stream);
 
+/* The same for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  NO COUNTERPART IN THE REFERENCE.  It runs the kernels of modes_convert_device(), but calls no hipMalloc /
+ * hipFree / allocating routine and never waits for the stream: the scratch those kernels need (table, power
+ * accumulator, the float converters' z1 sequences and squared magnitudes) is a fixed array in device memory, one per
+ * GPU, held until the process ends (about 3 MiB), and the results modes_convert_device() returns through host memory
+ * are written to *d_result in DEVICE memory by the last kernel of the call.
+ *   - nsamples > MODES_NOALLOC_MAX_SAMPLES is refused with MODES_E_ARG.
+ *   - DC_A, DC_B, z1_I, z1_Q: the fields of convert_state (DC_A = 0, DC_B = 1: DC block off); ignored by the integer
+ *     converters.
+ *   - runs on the CURRENT device.  The first call on a device uploads the tables (blocking) and must not be made
+ *     under capture.
+ *   - every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race. */
+#define MODES_NOALLOC_MAX_SAMPLES 262144
+typedef struct modes_convert_result {
+  double out_power;          /* what convert_func stores to *out_power       */
+  float  z1_I, z1_Q;         /* convert_state.z1_I / z1_Q after the call     */
+} modes_convert_result;
+int  modes_convert_device_noalloc (int converter_id, const void *d_iq, uint16_t *d_mag, size_t nsamples,
+                                   float DC_A, float DC_B, float z1_I, float z1_Q,
+                                   modes_convert_result *d_result /* device memory, may be NULL */, void *stream);
+
 /* messages queued by the drop-in demod_*() when no modeS_user_message callback is bound */
 size_t modes_hip_take_messages (modes_message *out, size_t max);
 
