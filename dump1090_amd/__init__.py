@@ -43,7 +43,7 @@ class Stats(C.Structure):
 
 class DcInfo(C.Structure):
     _fields_ = [("chunks", C.c_uint32), ("rerun_chunks", C.c_uint32), ("chunk_samples", C.c_uint64),
-                ("warm_samples", C.c_uint64), ("chain_ms", C.c_float), ("reserved", C.c_uint32),
+                ("warm_samples", C.c_uint64), ("chain_ms", C.c_float), ("prefix_reruns", C.c_uint32),
                 ("guess_rounds", C.c_uint64), ("plain_rounds", C.c_uint64), ("chain_steps", C.c_uint64)]
 
     def asdict(self):

@@ -179,8 +179,15 @@ struct D8Params {
 // One chain of the filter per chunk: it starts at sample `start` (<= the chunk's first sample, may reach back
 // into the lead-in in front of the shard) from the bracket [lo, hi] per channel; lo == hi when the state is known.
 constexpr int kDcBatch = 4096;         // samples a workgroup stages per round: sixteen per thread
-struct DcChunk { long long start; float zIlo, zIhi, zQlo, zQhi; uint32_t chunk; uint32_t pad; };
-static_assert(sizeof(DcChunk) == 32, "DcChunk must be 32 bytes");
+constexpr int kDcSeg = 65536;          // samples per segment of the real-arithmetic estimate (dc_linear_kernel)
+struct DcChunk {
+  long long start;                     // first sample the chain steps (<= the chunk's first sample)
+  float zIlo, zIhi, zQlo, zQhi;        // bracket in front of `start`
+  uint32_t chunk;                      // which chunk of the shard
+  uint32_t slot;                       // where the results of this chain go (z_start, z_end, unmerged, closed_at, z_close)
+  long long stop;                      // sample to stop in front of (a multiple of kDcBatch inside the chunk), or <= 0: the chunk's end
+};
+static_assert(sizeof(DcChunk) == 40, "DcChunk must be 40 bytes");
 
 struct DcParams {
   const uint8_t  *iq;          // sample 0 of the shard (16-byte aligned); `start` may be negative
@@ -189,9 +196,11 @@ struct DcParams {
   float           A, B;        // convert_state.DC_A, DC_B (ref: src/convert.c:349-353)
   const DcChunk  *desc;        // one per launched wave
   uint16_t       *mag;         // [n] magnitudes of the shard's samples (4-byte aligned)
-  float          *z_start;     // [nchunks][4] I-lo, I-hi, Q-lo, Q-hi in front of the chunk's first sample
-  float          *z_end;       // [nchunks][2] z1_I, z1_Q behind the chunk's last sample
-  uint32_t       *unmerged;    // [nchunks] 1 = the bracket was still open at the chunk's first sample
+  float          *z_start;     // [slots][4] I-lo, I-hi, Q-lo, Q-hi in front of the chunk's first sample
+  float          *z_end;       // [slots][2] z1_I, z1_Q behind the last sample stepped
+  uint32_t       *unmerged;    // [slots] 1 = the bracket was still open at the chunk's first sample
+  long long      *closed_at;   // [slots] first batch of the chunk in front of which both brackets were closed (-1: never)
+  float          *z_close;     // [slots][2] z1_I, z1_Q in front of that batch
   unsigned long long *ticks;   // [nchunks][16] profiling aid (wave 0: lifetime in clock ticks, guess rounds, plain rounds, ticks in the chain, at barriers); may be null
   unsigned long long *rounds;  // [2] guess rounds (256 samples tried), plain rounds (64 samples stepped one by one); may be null
 };

@@ -180,6 +180,11 @@ struct modes_engine {
   DevBuf<DcChunk> dc_desc;
   DevBuf<float> dc_zs, dc_ze;
   DevBuf<uint32_t> dc_unm;
+  DevBuf<double> dc_lin;
+  DevBuf<float> dc_zc;
+  DevBuf<long long> dc_closed;
+  DevBuf<unsigned long long> dc_ticks;
+  hipEvent_t dc_ev[2] = { nullptr, nullptr };
   float dc_A = 0.0f, dc_B = 1.0f, dc_z[2] = { 0.0f, 0.0f };
   uint64_t dc_lead = 0, dc_warm = 0;
   modes_dc_info dc_info;
@@ -322,90 +327,162 @@ int prepare_dc (modes_engine *e, const void *d_iq, size_t nbytes, const uint16_t
   if (K > kmax) K = kmax;
   const uint64_t L = ((n_eff + K - 1) / K + kDcBatch - 1) / kDcBatch * kDcBatch;
   K = (n_eff + L - 1) / L;
-  uint64_t warm = e->dc_warm ? e->dc_warm : uint64_t (std::ceil (35.0 / double (e->dc_A)));
+  // Warm-up: the bracket a chunk starts from is (where the filter is in real arithmetic) +- |z| / m, m = DC_A / 2^-24:
+  // RN (z * B) = z - k ulp with k an integer, so the float filter's leak is off by up to half an ulp per step, which
+  // the filter itself turns into at most 0.5 ulp / DC_A <= |z| / m.  A bracket that wide closes after about
+  // ln (2 / m * 2^24) / DC_A samples (13.5 time constants at 2.4 MS/s).  Chunks still open at their first sample are
+  // repaired below (only up to where they closed), so the length trades warm-up steps against repairs: 15.
+  double warm_tau = 15.0;
+  if (const char *ev = getenv ("MODES_DC_WARM_TAU")) if (atof (ev) > 0) warm_tau = atof (ev);
+  uint64_t warm = e->dc_warm ? e->dc_warm : uint64_t (std::ceil (warm_tau / double (e->dc_A)));
   warm = (warm + kDcBatch - 1) / kDcBatch * kDcBatch;
   const float bound = e->conv == kConvSc16Q11Generic ? 16.0f : 1.0f;  // |f| never exceeds it, so neither does |z1|
+
+  // where the filter is in real arithmetic at every segment boundary of [origin, n_eff), origin = -lead_eff
+  const uint64_t total = lead_eff + n_eff, nseg = (total + kDcSeg - 1) / kDcSeg;
+  std::vector<double> est (2 * (nseg + 1)), half (2 * (nseg + 1));     // value and half-width of the bracket, per channel
+  {
+    if ((rc = e->dc_lin.reserve (2 * nseg)) != MODES_OK) return rc;
+    HIP_TRY (launch_dc_linear (e->conv, static_cast<const uint8_t *> (d_iq) - (back + lead_eff) * bps, total, double (e->dc_A), double (e->dc_B),
+                               e->dc_lin.p, stream));
+    std::vector<double> S (2 * nseg);
+    HIP_TRY (hipMemcpyAsync (S.data (), e->dc_lin.p, 2 * nseg * sizeof (double), hipMemcpyDeviceToHost, stream));
+    HIP_TRY (hipStreamSynchronize (stream));
+    const double Bseg = std::pow (double (e->dc_B), double (kDcSeg));
+    const double rel = 1.25 / (double (e->dc_A) * 16777216.0);
+    for (int ch = 0; ch < 2; ch++) {
+      double E = lead == 0 ? double (e->dc_z[ch]) : 0.0;               // the stream's own state, or unknown
+      double U = lead == 0 ? 0.0 : double (bound);                     // what is not known about it
+      double M = std::fabs (E);                                        // the largest |z1| of the recent past, decaying like z1 itself
+      for (uint64_t j = 0; j <= nseg; j++) {
+        est[2 * j + ch] = E;
+        half[2 * j + ch] = rel * M + U + 1e-12 * double (bound);
+        if (j == nseg) break;
+        E = E * Bseg + S[2 * j + ch];
+        U *= Bseg;
+        M = std::max (M * Bseg, std::fabs (E));
+      }
+    }
+  }
+  auto lo_of = [&] (uint64_t j, int ch) { const float v = float (est[2 * j + ch] - half[2 * j + ch]); return std::max (-bound, std::nextafterf (v, -INFINITY)); };
+  auto hi_of = [&] (uint64_t j, int ch) { const float v = float (est[2 * j + ch] + half[2 * j + ch]); return std::min (bound, std::nextafterf (v, INFINITY)); };
+
   std::vector<DcChunk> desc (K);
   for (uint64_t c = 0; c < K; c++) {
     DcChunk &d = desc[c];
     const uint64_t c0 = c * L;
-    d.chunk = uint32_t (c); d.pad = 0;
-    if (c0 + lead_eff <= warm) {
-      d.start = -(long long) lead_eff;
-      if (lead == 0) { d.zIlo = d.zIhi = e->dc_z[0]; d.zQlo = d.zQhi = e->dc_z[1]; }       // the stream's own state
-      else           { d.zIlo = d.zQlo = -bound; d.zIhi = d.zQhi = bound; }
-    } else {
-      d.start = (long long) (c0 - warm);
-      d.zIlo = d.zQlo = -bound; d.zIhi = d.zQhi = bound;
-    }
+    d.chunk = uint32_t (c); d.slot = uint32_t (c); d.stop = 0;
+    uint64_t j = 0;                                                    // segment boundary the chain starts on
+    if (c0 + lead_eff > warm) j = (c0 + lead_eff - warm) / kDcSeg;
+    d.start = (long long) (j * kDcSeg) - (long long) lead_eff;
+    if (j == 0 && lead == 0) { d.zIlo = d.zIhi = e->dc_z[0]; d.zQlo = d.zQhi = e->dc_z[1]; }       // the stream's own state
+    else { d.zIlo = lo_of (j, 0); d.zIhi = hi_of (j, 0); d.zQlo = lo_of (j, 1); d.zQhi = hi_of (j, 1); }
   }
-  if ((rc = e->dc_desc.reserve (K + 1)) != MODES_OK) return rc;
-  if ((rc = e->dc_zs.reserve (4 * K)) != MODES_OK) return rc;
-  if ((rc = e->dc_ze.reserve (2 * K)) != MODES_OK) return rc;
-  if ((rc = e->dc_unm.reserve (K + 16)) != MODES_OK) return rc;
+  // slots 0 .. K-1: the chunks; K .. 2K-1: repairs of a chunk's first samples; 2K: a chunk re-run as a whole
+  if ((rc = e->dc_desc.reserve (2 * K + 1)) != MODES_OK) return rc;
+  if ((rc = e->dc_zs.reserve (4 * (2 * K + 1))) != MODES_OK) return rc;
+  if ((rc = e->dc_ze.reserve (2 * (2 * K + 1))) != MODES_OK) return rc;
+  if ((rc = e->dc_zc.reserve (2 * (2 * K + 1))) != MODES_OK) return rc;
+  if ((rc = e->dc_closed.reserve (2 * K + 1)) != MODES_OK) return rc;
+  if ((rc = e->dc_unm.reserve (2 * K + 1 + 16)) != MODES_OK) return rc;
   DcParams q;
   memset (&q, 0, sizeof q);
   q.iq = static_cast<const uint8_t *> (d_iq) - back * bps;
   q.n = n_eff; q.chunk_len = L; q.A = e->dc_A; q.B = e->dc_B;
   q.desc = e->dc_desc.p; q.mag = V + ov - back;
-  q.z_start = e->dc_zs.p; q.z_end = e->dc_ze.p; q.unmerged = e->dc_unm.p;
-  q.rounds = reinterpret_cast<unsigned long long *> (e->dc_unm.p + ((K + 1) & ~1ull));
+  q.z_start = e->dc_zs.p; q.z_end = e->dc_ze.p; q.unmerged = e->dc_unm.p; q.closed_at = e->dc_closed.p; q.z_close = e->dc_zc.p;
+  q.rounds = reinterpret_cast<unsigned long long *> (e->dc_unm.p + ((2 * K + 2) & ~1ull));
   HIP_TRY (hipMemsetAsync (q.rounds, 0, 6 * sizeof (unsigned long long), stream));
-  unsigned long long *d_ticks = nullptr;
-  if (getenv ("MODES_DC_PROFILE")) { HIP_TRY (hipMalloc (reinterpret_cast<void **> (&d_ticks), 16 * K * sizeof (unsigned long long))); HIP_TRY (hipMemset (d_ticks, 0, 16 * K * sizeof (unsigned long long))); }
-  q.ticks = d_ticks;
-  hipEvent_t ea, eb;
-  HIP_TRY (hipEventCreate (&ea));
-  HIP_TRY (hipEventCreate (&eb));
+  const bool profile = getenv ("MODES_DC_PROFILE") != nullptr;
+  if (profile) {
+    if ((rc = e->dc_ticks.reserve (16 * K)) != MODES_OK) return rc;
+    HIP_TRY (hipMemsetAsync (e->dc_ticks.p, 0, 16 * K * sizeof (unsigned long long), stream));
+    q.ticks = e->dc_ticks.p;
+  }
+  if (!e->dc_ev[0]) { HIP_TRY (hipEventCreate (&e->dc_ev[0])); HIP_TRY (hipEventCreate (&e->dc_ev[1])); }
   HIP_TRY (hipMemcpyAsync (e->dc_desc.p, desc.data (), K * sizeof (DcChunk), hipMemcpyHostToDevice, stream));
-  HIP_TRY (hipEventRecord (ea, stream));
+  HIP_TRY (hipEventRecord (e->dc_ev[0], stream));
   HIP_TRY (launch_dc_chain (e->conv, q, uint32_t (K), stream));
-  HIP_TRY (hipEventRecord (eb, stream));
-  std::vector<float> zs (4 * K), ze (2 * K);
+  HIP_TRY (hipEventRecord (e->dc_ev[1], stream));
+  // read-backs land in vectors that outlive every wait below: an early return synchronises first (SyncOnExit)
+  struct SyncOnExit { hipStream_t s; ~SyncOnExit () { (void) hipStreamSynchronize (s); } } sync_guard { stream };
+  std::vector<float> zs (4 * K), ze (2 * K), zc (2 * K);
   std::vector<uint32_t> unm (K);
+  std::vector<long long> closed (K);
+  unsigned long long rounds[6] = { 0, 0, 0, 0, 0, 0 };
+  HIP_TRY (hipMemcpyAsync (zc.data (), e->dc_zc.p, 2 * K * sizeof (float), hipMemcpyDeviceToHost, stream));
+  HIP_TRY (hipMemcpyAsync (closed.data (), e->dc_closed.p, K * sizeof (long long), hipMemcpyDeviceToHost, stream));
   HIP_TRY (hipMemcpyAsync (zs.data (), e->dc_zs.p, 4 * K * sizeof (float), hipMemcpyDeviceToHost, stream));
   HIP_TRY (hipMemcpyAsync (ze.data (), e->dc_ze.p, 2 * K * sizeof (float), hipMemcpyDeviceToHost, stream));
   HIP_TRY (hipMemcpyAsync (unm.data (), e->dc_unm.p, K * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
-  unsigned long long rounds[6] = { 0, 0, 0, 0, 0, 0 };
   HIP_TRY (hipMemcpyAsync (rounds, q.rounds, sizeof rounds, hipMemcpyDeviceToHost, stream));
   HIP_TRY (hipStreamSynchronize (stream));
-  (void) hipEventElapsedTime (&e->dc_info.chain_ms, ea, eb);
-  (void) hipEventDestroy (ea);
-  (void) hipEventDestroy (eb);
+  (void) hipEventElapsedTime (&e->dc_info.chain_ms, e->dc_ev[0], e->dc_ev[1]);
   e->dc_info.chunks = uint32_t (K); e->dc_info.chunk_samples = L; e->dc_info.warm_samples = warm;
   e->dc_info.guess_rounds = rounds[0]; e->dc_info.plain_rounds = rounds[1];
-  if (d_ticks) {
+  if (profile) {
     std::vector<unsigned long long> tk (16 * K);
-    HIP_TRY (hipMemcpy (tk.data (), d_ticks, 16 * K * sizeof (unsigned long long), hipMemcpyDeviceToHost));
-    (void) hipFree (d_ticks);
+    HIP_TRY (hipMemcpy (tk.data (), e->dc_ticks.p, 16 * K * sizeof (unsigned long long), hipMemcpyDeviceToHost));
     std::vector<uint64_t> order (K);
     for (uint64_t c = 0; c < K; c++) order[c] = c;
     std::sort (order.begin (), order.end (), [&] (uint64_t a, uint64_t b) { return tk[16 * a] > tk[16 * b]; });
-    for (uint64_t i = 0; i < K && i < 12; i++) {
+    for (uint64_t i = 0; i < K && i < 6; i++) {
       const uint64_t c = order[i];
-      fprintf (stderr, "  slowest: chunk %4llu: %9llu ticks, %7llu guesses, %6llu plain, chain %llu, barriers %llu; guesses/plain per wave %llu/%llu %llu/%llu %llu/%llu %llu/%llu\n", (unsigned long long) c, tk[16 * c], tk[16 * c + 1], tk[16 * c + 2], tk[16 * c + 3], tk[16 * c + 4],
-               tk[16 * c + 5], tk[16 * c + 6], tk[16 * c + 7], tk[16 * c + 8], tk[16 * c + 9], tk[16 * c + 10], tk[16 * c + 11], tk[16 * c + 12]);
+      fprintf (stderr, "  slowest: chunk %4llu: %9llu ticks, %7llu rounds, %6llu plain, chain %llu, barriers %llu\n", (unsigned long long) c, tk[16 * c], tk[16 * c + 1], tk[16 * c + 2], tk[16 * c + 3], tk[16 * c + 4]);
     }
-    for (uint64_t c = 0; c < K; c += (K > 16 ? K / 16 : 1))
-      fprintf (stderr, "  chunk %4llu: %9llu ticks, %7llu guesses, %6llu plain, %lld steps\n", (unsigned long long) c, tk[16 * c], tk[16 * c + 1], tk[16 * c + 2],
-               (long long) std::min (n_eff, (c + 1) * L) - desc[c].start);
+    uint64_t open_chunks = 0;
+    for (uint64_t c = 0; c < K; c++) open_chunks += unm[c];
+    fprintf (stderr, "dc profile (wave 0 sums over %llu chunks): chain %llu barrier %llu total %llu ticks, longest %llu; warm %llu, %llu chunks with an open bracket\n",
+             (unsigned long long) K, rounds[2], rounds[3], rounds[4], rounds[5], (unsigned long long) warm, (unsigned long long) open_chunks);
   }
-  if (getenv ("MODES_DC_PROFILE")) fprintf (stderr, "dc profile (wave 0 sums over %llu chunks): chain %llu barrier %llu total %llu ticks, longest %llu\n", (unsigned long long) K, rounds[2], rounds[3], rounds[4], rounds[5]);
   for (uint64_t c = 0; c < K; c++) e->dc_info.chain_steps += 2 * uint64_t ((long long) std::min (n_eff, (c + 1) * L) - desc[c].start);
   q.rounds = nullptr;
   q.ticks = nullptr;
   if (unm[0]) return fail (MODES_E_ARG, "filter_dc: a lead-in of %llu samples does not settle the DC filter (about %llu needed)",
                            (unsigned long long) lead, (unsigned long long) warm);
+  // Chunks whose bracket closed only after their first sample: from `closed_at` on their values are final (closed
+  // brackets have met on the true state, if they held it), so only [first sample, closed_at) is stepped again, from
+  // the end state of the chunk before -- all such chunks in one launch.  A repair that does not arrive at the state
+  // the chunk closed on (a bracket that did not hold the true state) sends the chunk to the sequential pass below.
+  std::vector<uint8_t> good (K, 0);              // 1: right as it stands, given that the chunk before ends on ze[c - 1] as read back
+  good[0] = 1;
+  std::vector<DcChunk> fix;
+  std::vector<uint64_t> fix_of;
   for (uint64_t c = 1; c < K; c++) {
     const float *st = &zs[4 * c], *pe = &ze[2 * (c - 1)];
-    if (!unm[c] && st[0] == pe[0] && st[2] == pe[1]) continue;
-    DcChunk d;                                                        // re-run from the exact state
-    d.start = (long long) (c * L); d.chunk = uint32_t (c); d.pad = 0;
+    if (!unm[c]) { good[c] = st[0] == pe[0] && st[2] == pe[1]; continue; }
+    if (closed[c] <= (long long) (c * L)) continue;                   // never closed
+    DcChunk d;
+    d.start = (long long) (c * L); d.chunk = uint32_t (c); d.slot = uint32_t (K + fix.size ()); d.stop = closed[c];
     d.zIlo = d.zIhi = pe[0]; d.zQlo = d.zQhi = pe[1];
-    HIP_TRY (hipMemcpyAsync (e->dc_desc.p + K, &d, sizeof d, hipMemcpyHostToDevice, stream));
+    fix.push_back (d); fix_of.push_back (c);
+  }
+  if (!fix.empty ()) {
+    std::vector<float> fe (2 * fix.size ());
+    HIP_TRY (hipMemcpyAsync (e->dc_desc.p + K, fix.data (), fix.size () * sizeof (DcChunk), hipMemcpyHostToDevice, stream));
     q.desc = e->dc_desc.p + K;
+    HIP_TRY (launch_dc_chain (e->conv, q, uint32_t (fix.size ()), stream));
+    HIP_TRY (hipMemcpyAsync (fe.data (), e->dc_ze.p + 2 * K, fe.size () * sizeof (float), hipMemcpyDeviceToHost, stream));
+    HIP_TRY (hipStreamSynchronize (stream));
+    for (size_t i = 0; i < fix.size (); i++) {
+      const uint64_t c = fix_of[i];
+      good[c] = fe[2 * i] == zc[2 * c] && fe[2 * i + 1] == zc[2 * c + 1];
+    }
+    e->dc_info.prefix_reruns = uint32_t (fix.size ());
+  }
+  // in order: whatever is not proven is stepped again as a whole from the exact state; a chunk behind one whose end
+  // state changed is only good if it was built on the new value
+  std::vector<float> assumed (ze);               // the end states the `good` flags were formed against
+  for (uint64_t c = 1; c < K; c++) {
+    const float *pe = &ze[2 * (c - 1)];
+    if (good[c] && assumed[2 * (c - 1)] == pe[0] && assumed[2 * (c - 1) + 1] == pe[1]) continue;
+    DcChunk d;
+    d.start = (long long) (c * L); d.chunk = uint32_t (c); d.slot = uint32_t (2 * K); d.stop = 0;
+    d.zIlo = d.zIhi = pe[0]; d.zQlo = d.zQhi = pe[1];
+    HIP_TRY (hipMemcpyAsync (e->dc_desc.p + 2 * K, &d, sizeof d, hipMemcpyHostToDevice, stream));
+    q.desc = e->dc_desc.p + 2 * K;
     HIP_TRY (launch_dc_chain (e->conv, q, 1, stream));
-    HIP_TRY (hipMemcpyAsync (&ze[2 * c], e->dc_ze.p + 2 * c, 2 * sizeof (float), hipMemcpyDeviceToHost, stream));
+    HIP_TRY (hipMemcpyAsync (&ze[2 * c], e->dc_ze.p + 2 * (2 * K), 2 * sizeof (float), hipMemcpyDeviceToHost, stream));
     HIP_TRY (hipStreamSynchronize (stream));
     e->dc_info.rerun_chunks++;
   }
@@ -598,6 +675,8 @@ void modes_engine_destroy (modes_engine *e)
   e->block_power.release (); e->noise_level.release ();
   e->raw_len.release (); e->raw_off.release (); e->raw_cs.release (); e->raw_cv.release (); e->raw_co.release (); e->raw_text.release ();
   if (e->pin_text) (void) hipHostFree (e->pin_text);
+  e->dc_lin.release (); e->dc_ticks.release (); e->dc_zc.release (); e->dc_closed.release ();
+  for (hipEvent_t ev : e->dc_ev) if (ev) (void) hipEventDestroy (ev);
   e->dc_mag.release (); e->dc_desc.release (); e->dc_zs.release (); e->dc_ze.release (); e->dc_unm.release ();
   e->d8_trig.release (); e->d8_amb.release (); e->d8_off.release (); e->d8_p0.release (); e->d8_mx.release ();
   e->d8_win_count.release (); e->d8_chunk_rec.release (); e->d8_announce.release (); e->d8_table.release (); e->d8_entry.release ();

@@ -39,6 +39,7 @@ hipError_t launch_raw_format (const void *msgs, uint32_t n, uint32_t *len, uint6
                               uint64_t *chunk_ovf, uint64_t *totals, uint64_t *offsets, int upper, char *text, int pass, hipStream_t stream);
 // kernels_dc.hip
 hipError_t launch_dc_chain (int conv, const DcParams &p, uint32_t ndesc, hipStream_t stream);
+hipError_t launch_dc_linear (int conv, const uint8_t *iq, uint64_t n, double A, double B, double *out, hipStream_t stream);
 hipError_t launch_accept2400 (const AcceptParams &p, hipStream_t stream);
 hipError_t launch_snapshots (const uint32_t *delta, uint32_t nblocks, const uint32_t *cache_in, uint32_t *chunk_last,
                              uint32_t *chunk_entry, uint32_t *snap_in, uint32_t *cache_out, uint32_t *dirty, hipStream_t stream);

@@ -7,18 +7,17 @@
 //
 //   g(z) = RN (t + RN (z * B))   is monotone non-decreasing in z  (RN = round to nearest, B > 0).
 //
-// A chunk of the stream therefore starts its chain `warm` samples early from a bracket lo <= z <= hi that
-// is known to hold the true state (|z1| never exceeds the largest |f|), steps lo and hi through the very
-// float operations of the reference, and once lo == hi the value IS the reference's z1 -- whatever the
-// start was.  Chunks are independent; one workgroup of four waves runs one chunk, wave w one of the four chains
+// A chunk of the stream therefore starts its chain `warm` samples early from a bracket lo <= z <= hi around
+// where the filter is in real arithmetic (dc_linear_kernel), steps lo and hi through the very float operations of
+// the reference, and once lo == hi -- and the chunk before ends on the same value -- it IS the reference's z1,
+// whatever the start was (a bracket that missed is caught by the host's check and the chunk re-run).  Chunks are independent; one workgroup of four waves runs one chunk, wave w one of the four chains
 // I-lo, I-hi, Q-lo, Q-hi (the hi waves idle once their bracket has closed); all 256 threads fetch/convert the next
 // 4096 samples and form the magnitudes behind the chains.
-// A chunk whose bracket has not closed at its first sample is reported (`unmerged`) and re-run by the
+// A chunk whose bracket has not closed at its first sample is reported (`unmerged`, `closed_at`) and repaired by the
 // host from the exact end state of the chunk before it.
 //
-// A chain is a latency problem: two dependent operations per sample.  A wave therefore steps 1024 samples at once,
-// sixteen per lane, from guessed lane starts and keeps what it can prove (see dc_round below); where the guesses
-// keep failing (z1 next to zero, or sitting on a boundary of the product's rounding) it steps plainly for a while.
+// A chain is two dependent operations per sample.  A wave therefore steps 1024 samples at once, sixteen per lane,
+// from guessed lane starts that it refines until it can prove them (see dc_round below).
 //
 // "ref:" citations are relative to the reference's root.
 #include <hip/hip_runtime.h>
@@ -83,130 +82,85 @@ __device__ __forceinline__ float wave_incl_scan_f (float v)
 __device__ __forceinline__ int dcp (int i) { return i; }
 constexpr int kDcBatchLds = kDcBatch;
 
-constexpr int kDcPer = 16;                      // consecutive samples per lane in one guess
-constexpr int kDcRound = 64 * kDcPer;           // samples per guess
+constexpr int kDcPer = 16;                      // consecutive samples per lane in one round
+constexpr int kDcRound = 64 * kDcPer;           // samples per round
+constexpr int kDcIters = 4;                     // refinements of the lanes' start values per round
 
 __device__ __forceinline__ float bcast_lane (float x, int l)
 {
   return __uint_as_float (uint32_t (__builtin_amdgcn_readlane (int (__float_as_uint (x)), l)));
 }
 
-// ---- one round of a chain: kDcRound samples, kDcPer consecutive ones per lane ----------------------------------
+// ---- one round of a chain: up to kDcRound samples, kDcPer consecutive ones per lane ----------------------------
 // Every lane steps its own samples with the REAL operations (ref: src/convert.c:137-140), so what happens inside a
 // lane -- ties of the rounding included -- is the reference's arithmetic; only the value a lane STARTS from is
-// guessed.  While z1 stays inside one binade and RN (z * B) keeps its distance to z, moving the start by a whole
-// number of ulps moves every later value by the same amount, except that a tie of RN (t + z * B) falls the other
-// way when the start moves by an odd number.  So each lane first steps its samples from z0 and from z0 + 1 ulp:
-// that yields its increment and the parity of its increment for an even and for an odd start offset, i.e. a map
-// (offset parity in) -> (offset parity out, increment).  The maps compose associatively; a scan over the lanes gives
-// every lane its start offset, the lane steps again from there, and the round is accepted up to the first lane
-// whose start differs, bit for bit, from the value the lane below ended on (exact by induction from z0).
-struct DcMap { uint32_t n; float d0, d1; };        // n bit p: the parity flips for an input parity p; d_p: increment
-
-__device__ __forceinline__ DcMap dc_compose (const DcMap y, const DcMap x)      // y first, then x
+// guessed.  The guesses are refined: a lane's increment (end - start) depends on its start only through the few
+// places where RN (z * B) or a tie falls differently, so  start[l] = z0 + sum of the increments of the lanes below
+// converges in two to three passes even where z1 sits on a boundary of the product's rounding -- which is where the
+// filter settles whenever the input has a DC component: RN (z * B) = z - k ulp with k = round (z * (1 - B) / ulp), the
+// mean of RN (t) falls between two integers, and z1 dithers across the point where k changes.
+// A pass is accepted up to the first lane whose start differs, bit for bit, from the value the lane below ended on:
+// exact by induction from z0, whatever the guesses were.
+// tk[q] = t of sample kDcPer * lane + q; nl = lanes that hold samples.  On return zt[q] = z1 behind that sample as
+// stepped from the lane's start; the result is the number of leading lanes whose values are proven (>= 1).
+__device__ __forceinline__ int dc_round (const float *tk, float z0, float B, int lane, int nl, float *zt)
 {
-  DcMap o;
-  const bool f0 = y.n & 1u, f1 = y.n & 2u;         // parity after y for inputs 0, 1 is 0 ^ f0, 1 ^ f1
-  const uint32_t x0 = f0 ? (x.n >> 1) & 1u : x.n & 1u;          // x's flip at parity (0 ^ f0)
-  const uint32_t x1 = f1 ? x.n & 1u : (x.n >> 1) & 1u;          // x's flip at parity (1 ^ f1)
-  o.n = ((y.n & 1u) ^ x0) | ((((y.n >> 1) & 1u) ^ x1) << 1);
-  o.d0 = __fadd_rn (y.d0, f0 ? x.d1 : x.d0);
-  o.d1 = __fadd_rn (y.d1, f1 ? x.d0 : x.d1);
-  return o;
-}
-
-template <int CTRL, int MASK, bool BOUND>
-__device__ __forceinline__ DcMap dc_map_dpp (const DcMap x)
-{
-  DcMap y;
-  y.n = dpp_mov<CTRL, MASK, BOUND> (x.n);
-  y.d0 = __uint_as_float (dpp_mov<CTRL, MASK, BOUND> (__float_as_uint (x.d0)));
-  y.d1 = __uint_as_float (dpp_mov<CTRL, MASK, BOUND> (__float_as_uint (x.d1)));
-  return y;
-}
-
-// inclusive scan of the lanes' maps (all-zero = the identity, which is what DPP fills in)
-__device__ __forceinline__ DcMap dc_map_scan (DcMap x)
-{
-  x = dc_compose (dc_map_dpp<0x111, 0xF, true> (x), x);
-  x = dc_compose (dc_map_dpp<0x112, 0xF, true> (x), x);
-  x = dc_compose (dc_map_dpp<0x114, 0xF, true> (x), x);
-  x = dc_compose (dc_map_dpp<0x118, 0xF, true> (x), x);
-  x = dc_compose (dc_map_dpp<0x142, 0xA, false> (x), x);
-  x = dc_compose (dc_map_dpp<0x143, 0xC, false> (x), x);
-  return x;
-}
-
-// tk[q] = t of sample kDcPer * lane + q.  On return zt[q] = z1 behind that sample as stepped from the lane's start;
-// the result is the number of leading lanes whose values are proven (64 = the whole round).
-__device__ __forceinline__ int dc_round (const float *tk, float z0, float B, int lane, float *zt)
-{
-  const uint32_t zb = __float_as_uint (z0);
-  const float z1u = __uint_as_float (zb + 1u);                   // one ulp further from zero: the odd start
-  float za = z0, zo = z1u;
+  // first guess: the filter in real arithmetic, z' = z + t - z (1 - B), with z ~ z0 over the round
+  float start;
+  {
+    float ts = 0.0f;
 #pragma unroll
-  for (int q = 0; q < kDcPer; q++) {
-    za = __fadd_rn (tk[q], __fmul_rn (za, B));
-    zo = __fadd_rn (tk[q], __fmul_rn (zo, B));
+    for (int q = 0; q < kDcPer; q++) ts += tk[q];
+    const float leak = z0 - z0 * B;
+    const float inc = ts - float (kDcPer) * leak;
+    const float incl = wave_incl_scan_f (inc);
+    start = z0 + (incl - inc);
   }
-  DcMap mp;
-  mp.d0 = __fsub_rn (za, z0);
-  mp.d1 = __fsub_rn (zo, z1u);
-  mp.n = ((__float_as_uint (za) ^ zb) & 1u) | (((__float_as_uint (zo) ^ zb ^ 1u) & 1u) << 1);
-  const DcMap in = dc_map_scan (mp);
-  DcMap ex = dc_map_dpp<0x138, 0xF, true> (in);                  // wave_shr:1: the lanes below
-  if (lane == 0) { ex.n = 0; ex.d0 = 0.0f; ex.d1 = 0.0f; }
-  // the chain enters the round at offset 0 (even): start of this lane = z0 + increment of the lanes below
-  const float start = __fadd_rn (z0, ex.d0);
-  float z = start;
+  int good = 1;
+#pragma unroll 1
+  for (int it = 0; it < kDcIters; it++) {
+    float z = start;
 #pragma unroll
-  for (int q = 0; q < kDcPer; q++) { z = __fadd_rn (tk[q], __fmul_rn (z, B)); zt[q] = z; }
-  float below = __uint_as_float (dpp_mov<0x138, 0xF, true> (__float_as_uint (z)));
-  if (lane == 0) below = z0;
-  const u64 bad = __ballot (__float_as_uint (below) != __float_as_uint (start));
-  return bad ? __builtin_ctzll (bad) : 64;
+    for (int q = 0; q < kDcPer; q++) { z = __fadd_rn (tk[q], __fmul_rn (z, B)); zt[q] = z; }
+    float below = __uint_as_float (dpp_mov<0x138, 0xF, true> (__float_as_uint (z)));     // wave_shr:1: the lane below
+    if (lane == 0) below = z0;
+    const u64 bad = __ballot (__float_as_uint (below) != __float_as_uint (start) && lane < nl);
+    good = bad ? __builtin_ctzll (bad) : nl;
+    if (good == nl || it == kDcIters - 1) break;
+    const float inc = __fsub_rn (z, start);
+    const float incl = wave_incl_scan_f (inc);
+    start = __fadd_rn (z0, __fsub_rn (incl, inc));
+  }
+  return good;
 }
 
 // One chain over t[0 .. cnt): returns z1 behind the last sample, zo[i] = z1 behind sample i.  z0 is uniform.
-// t and zo are 16-byte aligned.
-__device__ __forceinline__ float dc_chain_batch (const float *t, float *zo, bool store, int cnt, float z0, float B, int lane, uint32_t &n_guess, uint32_t &n_plain, int &backoff)
+// t and zo are 16-byte aligned and hold kDcBatch entries (entries at and beyond cnt are never used in a result).
+__device__ __forceinline__ float dc_chain_batch (const float *t, float *zo, bool store, int cnt, float z0, float B, int lane, uint32_t &n_guess, uint32_t &n_plain)
 {
-  int base = 0, plain = 0;
+  int base = 0;
   while (base < cnt) {
     const int rem = cnt - base;
-    if (plain || rem < kDcRound || (base & 3)) {  // plain steps (ref: src/convert.c:137-140), then guess again
-      int m = plain ? 64 * plain : rem < kDcRound ? rem : 4 - (base & 3);
-      if (m > rem) m = rem;
-      // every lane steps the same chain: a dependent VALU operation of a wave with one active lane takes four times
-      // as long as one with all lanes active (tools/ubench/dep_latency2.hip: 35 against 8.6 cycles per step)
+    if (rem < kDcPer) {                            // ragged end of the stream: plain steps (ref: src/convert.c:137-140)
       float z = z0;
       const bool st = store && lane == 0;
-      int i = 0;
-      for (; i < m && ((base + i) & 3); i++) { z = __fadd_rn (t[dcp (base + i)], __fmul_rn (z, B)); if (st) zo[dcp (base + i)] = z; }
-      float4 nx = i + 4 <= m ? *reinterpret_cast<const float4 *> (t + dcp (base + i)) : make_float4 (0.0f, 0.0f, 0.0f, 0.0f);
-      for (; i + 4 <= m; i += 4) {
-        const float4 x = nx;
-        if (i + 8 <= m) nx = *reinterpret_cast<const float4 *> (t + dcp (base + i + 4));  // in flight behind the four steps
-        float4 o;
-        z = __fadd_rn (x.x, __fmul_rn (z, B)); o.x = z;
-        z = __fadd_rn (x.y, __fmul_rn (z, B)); o.y = z;
-        z = __fadd_rn (x.z, __fmul_rn (z, B)); o.z = z;
-        z = __fadd_rn (x.w, __fmul_rn (z, B)); o.w = z;
-        if (st) *reinterpret_cast<float4 *> (zo + dcp (base + i)) = o;
-      }
-      for (; i < m; i++) { z = __fadd_rn (t[dcp (base + i)], __fmul_rn (z, B)); if (st) zo[dcp (base + i)] = z; }
+      for (int i = 0; i < rem; i++) { z = __fadd_rn (t[dcp (base + i)], __fmul_rn (z, B)); if (st) zo[dcp (base + i)] = z; }
       z0 = z;
-      base += m; n_plain += uint32_t ((m + 63) / 64); plain = 0;
+      base += rem; n_plain++;
       continue;
     }
     n_guess++;
+    const int nl = rem >= kDcRound ? 64 : rem / kDcPer;          // lanes that hold samples of this batch
     float tk[kDcPer], zt[kDcPer];
-    {
+    if (lane < nl) {
       const float4 *src = reinterpret_cast<const float4 *> (t + dcp (base + kDcPer * lane));
 #pragma unroll
       for (int g = 0; g < kDcPer / 4; g++) { const float4 x = src[g]; tk[4 * g] = x.x; tk[4 * g + 1] = x.y; tk[4 * g + 2] = x.z; tk[4 * g + 3] = x.w; }
+    } else {
+#pragma unroll
+      for (int q = 0; q < kDcPer; q++) tk[q] = 0.0f;
     }
-    const int good = dc_round (tk, z0, B, lane, zt);             // >= 1: lane 0 starts from z0 itself
+    const int good = dc_round (tk, z0, B, lane, nl, zt);         // >= 1: lane 0 starts from z0 itself
     if (store && lane < good) {
       float4 *dst = reinterpret_cast<float4 *> (zo + dcp (base + kDcPer * lane));
 #pragma unroll
@@ -214,10 +168,6 @@ __device__ __forceinline__ float dc_chain_batch (const float *t, float *zo, bool
     }
     z0 = bcast_lane (zt[kDcPer - 1], good - 1);
     base += kDcPer * good;
-    // a round that got nowhere: step plainly for a while, twice as long every time it happens again (z1 sitting on a
-    // boundary of the product's rounding, or next to zero, fails round after round)
-    if (good < 16) { backoff = backoff ? (backoff < 32 ? 2 * backoff : 32) : 1; plain = backoff; }
-    else if (good >= 32) backoff = 0;
   }
   return z0;
 }
@@ -236,11 +186,11 @@ void dc_chain_kernel (const DcParams p)
   if (tid == 0) { s_state[0] = d.zIlo; s_state[1] = d.zIhi; s_state[2] = d.zQlo; s_state[3] = d.zQhi; }
   __syncthreads ();
   const long long c0 = (long long) d.chunk * (long long) p.chunk_len;
-  const long long c1 = min (c0 + (long long) p.chunk_len, (long long) p.n);
+  const long long c1 = d.stop > 0 ? d.stop : min (c0 + (long long) p.chunk_len, (long long) p.n);
+  bool noted = false;
   float z = wv == 0 ? d.zIlo : wv == 1 ? d.zIhi : wv == 2 ? d.zQlo : d.zQhi;
   const float A = p.A, B = p.B;
   uint32_t n_guess = 0, n_plain = 0;
-  int backoff = 0;
   long long tm_chain = 0, tm_bar = 0, tm_total = clock64 ();
 
   constexpr int NG = kDcBatch / 1024;                                // groups of 1024 samples: four per thread each
@@ -266,15 +216,19 @@ void dc_chain_kernel (const DcParams p)
     tm_bar += clock64 () - tb;
     const bool region = b >= c0;
     if (b == c0 && tid == 0) {            // first sample of the chunk: have the brackets closed?
-      float *zs = p.z_start + 4 * size_t (d.chunk);
+      float *zs = p.z_start + 4 * size_t (d.slot);
       zs[0] = sIlo; zs[1] = sIhi; zs[2] = sQlo; zs[3] = sQhi;
-      p.unmerged[d.chunk] = (sIlo == sIhi && sQlo == sQhi) ? 0u : 1u;
+      p.unmerged[d.slot] = (sIlo == sIhi && sQlo == sQhi) ? 0u : 1u;
+    }
+    if (region && !noted && sIlo == sIhi && sQlo == sQhi) {       // from here on the chunk's values are final
+      noted = true;
+      if (tid == 0) { p.closed_at[d.slot] = b; p.z_close[2 * size_t (d.slot)] = sIlo; p.z_close[2 * size_t (d.slot) + 1] = sQlo; }
     }
     const int cnt = int (min ((long long) kDcBatch, c1 - b));
     const bool closed = (wv & 1) && (wv == 1 ? sIlo == sIhi : sQlo == sQhi);     // a hi chain that has met its lo chain
     if (!closed) {
       const long long tc = clock64 ();
-      z = dc_chain_batch (s_t[wv >> 1], s_z[wv >> 1], !(wv & 1), cnt, z, B, lane, n_guess, n_plain, backoff);
+      z = dc_chain_batch (s_t[wv >> 1], s_z[wv >> 1], !(wv & 1), cnt, z, B, lane, n_guess, n_plain);
       if (lane == 0) {
         s_state[wv] = z;
         if (!(wv & 1) && (wv == 0 ? sIlo == sIhi : sQlo == sQhi)) s_state[wv + 1] = z;   // the closed hi chain follows
@@ -309,10 +263,67 @@ void dc_chain_kernel (const DcParams p)
     }
   }
   __syncthreads ();
-  if (tid == 0) { p.z_end[2 * size_t (d.chunk)] = s_state[0]; p.z_end[2 * size_t (d.chunk) + 1] = s_state[2]; }
+  if (tid == 0) {
+    p.z_end[2 * size_t (d.slot)] = s_state[0]; p.z_end[2 * size_t (d.slot) + 1] = s_state[2];
+    if (!noted) p.closed_at[d.slot] = -1;
+  }
   if (lane == 0 && p.ticks) { unsigned long long *o = p.ticks + 16 * size_t (d.chunk) + 5 + 2 * wv; o[0] = n_guess; o[1] = n_plain; }
   if (lane == 0 && p.rounds) { atomicAdd (&p.rounds[0], (unsigned long long) n_guess); atomicAdd (&p.rounds[1], (unsigned long long) n_plain);
     if (wv == 0) { atomicAdd (&p.rounds[2], (unsigned long long) tm_chain); atomicAdd (&p.rounds[3], (unsigned long long) tm_bar); atomicAdd (&p.rounds[4], (unsigned long long) (clock64 () - tm_total)); atomicMax (&p.rounds[5], (unsigned long long) (clock64 () - tm_total)); if (p.ticks) { unsigned long long *o = p.ticks + 16 * size_t (d.chunk); o[0] = (unsigned long long) (clock64 () - tm_total); o[1] = n_guess; o[2] = n_plain; o[3] = (unsigned long long) tm_chain; o[4] = (unsigned long long) tm_bar; } } }
+}
+
+// ---- where the filter would be in real arithmetic ---------------------------------------------------------------
+// z1 behind a segment = z1 in front of it * B^len + sum over its samples of f * A * B^(len - 1 - i): the sums of all
+// segments are independent (double precision here), the host chains them.  The float filter follows that value to
+// within a few per cent (it settles where RN (z * B) changes its step, see dc_round), which is what the chunks'
+// starting brackets are built from.  One workgroup per segment of kDcSeg samples.
+template <int CONV>
+__global__ __launch_bounds__ (256)
+void dc_linear_kernel (const uint8_t *iq, long long n, double A, double B, double *out /* [segments][2] */)
+{
+  __shared__ float s_uc8[256];
+  __shared__ double s_part[2][4];
+  const int tid = threadIdx.x;
+  if (CONV == kConvUc8Generic) s_uc8[tid] = float ((double (tid) - 127.5) / 127.5);
+  __syncthreads ();
+  const long long s0 = (long long) blockIdx.x * kDcSeg;
+  const long long s1 = min (s0 + (long long) kDcSeg, n);
+  // sample 1024 g + 4 tid + k of the segment carries the weight B^(kDcSeg - 1 - that): Horner over g with B^1024
+  double w[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) w[k] = pow (B, double (1023 - 4 * tid - k));
+  const double B1024 = pow (B, 1024.0);
+  double aI = 0.0, aQ = 0.0;
+  for (int g = 0; g < kDcSeg / 1024; g++) {
+    DcRaw<CONV> raw;
+    dc_load4<CONV> (iq, s0 + 1024 * g + 4 * tid, s1, raw);       // zeros beyond the end of the stream
+    float fI[4], fQ[4];
+    dc_to_float<CONV> (raw, s_uc8, fI, fQ);
+    double sI = 0.0, sQ = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const bool in = s0 + 1024 * g + 4 * tid + k < s1;
+      sI += in ? double (fI[k]) * w[k] : 0.0; sQ += in ? double (fQ[k]) * w[k] : 0.0;
+    }
+    aI = aI * B1024 + sI; aQ = aQ * B1024 + sQ;
+  }
+  for (int d = 32; d >= 1; d >>= 1) { aI += __shfl_xor (aI, d, 64); aQ += __shfl_xor (aQ, d, 64); }
+  if ((tid & 63) == 0) { s_part[0][tid >> 6] = aI; s_part[1][tid >> 6] = aQ; }
+  __syncthreads ();
+  if (tid < 2) out[2 * size_t (blockIdx.x) + tid] = A * (s_part[tid][0] + s_part[tid][1] + s_part[tid][2] + s_part[tid][3]);
+}
+
+hipError_t launch_dc_linear (int conv, const uint8_t *iq, uint64_t n, double A, double B, double *out, hipStream_t stream)
+{
+  if (n == 0) return hipSuccess;
+  const dim3 grid ((unsigned) ((n + kDcSeg - 1) / kDcSeg)), block (256);
+  switch (conv) {
+    case kConvUc8Generic:     hipLaunchKernelGGL (dc_linear_kernel<kConvUc8Generic>, grid, block, 0, stream, iq, (long long) n, A, B, out); break;
+    case kConvSc16Generic:    hipLaunchKernelGGL (dc_linear_kernel<kConvSc16Generic>, grid, block, 0, stream, iq, (long long) n, A, B, out); break;
+    case kConvSc16Q11Generic: hipLaunchKernelGGL (dc_linear_kernel<kConvSc16Q11Generic>, grid, block, 0, stream, iq, (long long) n, A, B, out); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError ();
 }
 
 hipError_t launch_dc_chain (int conv, const DcParams &p, uint32_t ndesc, hipStream_t stream)

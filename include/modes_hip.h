@@ -254,12 +254,12 @@ int  modes_engine_get_dc_state (const modes_engine *e, float *z1_I, float *z1_Q)
 int  modes_engine_set_dc_lead (modes_engine *e, uint64_t lead_samples, uint64_t warm_samples);
 typedef struct modes_dc_info {
   uint32_t chunks;           /* independent chains of the last run                            */
-  uint32_t rerun_chunks;     /* chunks re-run from the exact end state of their predecessor   */
+  uint32_t rerun_chunks;     /* chunks re-run as a whole from the exact end state of their predecessor */
   uint64_t chunk_samples, warm_samples;
   float    chain_ms;         /* duration of the chain kernel (HIP events on the launch stream) */
-  uint32_t reserved;
-  uint64_t guess_rounds;     /* 256-sample guesses tried by all chains of the first pass          */
-  uint64_t plain_rounds;     /* 64-sample runs stepped one by one after a guess got nowhere       */
+  uint32_t prefix_reruns;    /* chunks whose first samples (up to where their bracket closed) were stepped again */
+  uint64_t guess_rounds;     /* 1024-sample rounds of all chains of the first pass                */
+  uint64_t plain_rounds;     /* ragged ends stepped one by one                                     */
   uint64_t chain_steps;      /* filter steps of all chains of the first pass (warm-up included)  */
 } modes_dc_info;
 int  modes_engine_get_dc_info (const modes_engine *e, modes_dc_info *out);

@@ -70,7 +70,8 @@ def test_short_warmup_is_repaired(warm):
     e = check_run(iq, "uc8", 2400000, warm=warm, expect_min_msgs=100)
     info = e.dc_info()
     assert info["chunks"] >= 8 and info["warm_samples"] == warm
-    assert info["rerun_chunks"] >= info["chunks"] - 1 - (warm + info["chunk_samples"] - 1) // info["chunk_samples"]
+    repaired = info["rerun_chunks"] + info["prefix_reruns"]
+    assert repaired >= info["chunks"] - 1 - (warm + 65536 + info["chunk_samples"] - 1) // info["chunk_samples"]
 
 
 @pytest.mark.parametrize("nsamples", [0, 1, 255, 256, 257, 4099, 65536, 131072 + 331])
@@ -100,8 +101,9 @@ def test_demod_8000_behind_dc_converter():
 
 
 def test_long_recording_brackets_close():
-    """40 M samples at 2.4 MS/s: chunks beyond ~13.4 M samples start from the bracket [-1, 1] and must have
-    closed on the reference's exact state by their first sample."""
+    """40 M samples at 2.4 MS/s: chunks beyond the warm-up length start from a bracket around the filter's value in
+    real arithmetic and must have closed on the reference's exact state by their first sample, or soon behind it
+    (then only those first samples are stepped again)."""
     import torch
     from dump1090_amd import synth_torch
     n = 40_000_000
@@ -116,7 +118,8 @@ def test_long_recording_brackets_close():
     bad = np.flatnonzero(got != exp)
     assert bad.size == 0, "first differing sample %d (%d differ); %r" % (bad[0], bad.size, info)
     assert e.get_dc_state() == zexp
-    assert info["chunks"] >= 128 and info["rerun_chunks"] <= 2, info
+    # nearly all chunks are right as first stepped; the few whose bracket closed late are repaired
+    assert info["chunks"] >= 128 and info["rerun_chunks"] + info["prefix_reruns"] <= info["chunks"] // 10, info
     emsg, _ = oracle_run(iq, "uc8", filter_dc=True, compute_power=True)
     assert len(emsg) > 5000
     assert_same_messages(e.messages(), emsg)
