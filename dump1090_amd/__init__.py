@@ -143,6 +143,8 @@ def lib():
                                            C.POINTER(C.c_double), C.c_void_p]
         L.modes_convert_device_noalloc.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float,
                                                    C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.modes_strip_device.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint64), C.c_void_p,
+                                         C.POINTER(C.c_size_t), C.c_void_p]
         L.modes_hip_bind.argtypes = [C.c_void_p]
         L.convert_init.restype = C.c_void_p
         L.convert_init.argtypes = [C.c_int, C.c_double, C.c_bool, C.c_bool, C.POINTER(C.POINTER(ConvertState))]
@@ -290,6 +292,14 @@ def convert_device(conv_id, d_iq_ptr, d_mag_ptr, nsamples, state=None, want_powe
                                       C.byref(state) if state is not None else None,
                                       C.byref(p) if want_power else None, C.c_void_p(stream) if stream else None))
     return p.value
+
+
+def strip_device(d_iq_ptr, nbytes, level, d_out_ptr, run=0, stream=None):
+    """modes_strip_device(): returns (bytes written, run of quiet pairs carried out)."""
+    r, n = C.c_uint64(run), C.c_size_t(0)
+    _check(lib().modes_strip_device(C.c_void_p(d_iq_ptr), nbytes, int(level), C.byref(r), C.c_void_p(d_out_ptr), C.byref(n),
+                                    C.c_void_p(stream) if stream else None))
+    return int(n.value), int(r.value)
 
 
 NOALLOC_MAX_SAMPLES = 262144

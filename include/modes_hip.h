@@ -274,6 +274,14 @@ int  modes_engine_read_dc_magnitudes (modes_engine *e, uint16_t *out, size_t fir
  * cannot wait for the previous shard's tail.  at_sample must be a multiple of the block length. */
 int  modes_engine_halo_at (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t at_sample, uint16_t *d_out, void *stream);
 
+/* --strip as a streaming pass (ref: src/dump1090.c:3423-3448, strip_mode_loop; README "What is --strip mode?"):
+ * uc8 IQ pairs whose I and Q both lie within `level` of 127 are dropped from the 33rd pair of such a run on, all other
+ * pairs are copied in order.  d_iq (16-byte aligned) and d_out (room for nbytes) are device memory; *out_bytes receives
+ * the bytes written.  *run_io (may be NULL = 0) is the reference's counter of quiet pairs in a row, carried from one
+ * piece of a stream to the next (it comes back saturated at 32, which behaves like any longer run). */
+int  modes_strip_device (const void *d_iq, size_t nbytes, int level, uint64_t *run_io, void *d_out, size_t *out_bytes,
+                         void *stream);
+
 /* Stand-alone converter on device buffers: what convert_func computes, for n samples. */
 int  modes_convert_device (int converter_id /* row of converters_table, ref: src/convert.c:301-308 */,
                            const void *d_iq, uint16_t *d_mag, size_t nsamples,

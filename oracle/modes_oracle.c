@@ -251,6 +251,27 @@ void orc_icao_import (orc_ctx *c, const uint32_t *slots) { memcpy (c->icao, slot
 static uint16_t g_last_tail[4096]; static uint32_t g_last_tail_n;
 uint32_t orc_last_tail (uint16_t *out) { memcpy (out, g_last_tail, g_last_tail_n * sizeof (uint16_t)); return g_last_tail_n; }
 
+/* ref: src/dump1090.c:3423-3448 (strip_mode_loop): uc8 IQ pairs whose I and Q are both within `level` of 127 are
+ * dropped once more than 4 * MODES_PREAMBLE_US = 32 of them follow each other; everything else is copied.
+ * *run_io: the counter `c` of the reference (quiet samples in a row so far), carried from call to call.
+ * A trailing odd byte is not a pair and is ignored (the loop ends at the first EOF). */
+size_t orc_strip (const uint8_t *in, size_t nbytes, int level, uint64_t *run_io, uint8_t *out)
+{
+  uint64_t c = run_io ? *run_io : 0;
+  size_t o = 0;
+  for (size_t i = 0; i + 1 < nbytes; i += 2) {
+    const int I = in[i], Q = in[i + 1];
+    if (abs (I - 127) < level && abs (Q - 127) < level) {
+      c++;
+      if (c > 4 * 8) continue;
+    } else c = 0;
+    out[o++] = (uint8_t) I;
+    out[o++] = (uint8_t) Q;
+  }
+  if (run_io) *run_io = c;
+  return o;
+}
+
 void orc_reset (orc_ctx *c)
 {
   memset (c->icao, 0, sizeof c->icao);

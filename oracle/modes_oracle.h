@@ -142,6 +142,9 @@ void     orc_icao_export (const orc_ctx *c, uint32_t *slots1024);
 void     orc_icao_import (orc_ctx *c, const uint32_t *slots1024);
 uint32_t orc_last_tail (uint16_t *out);
 
+/* ---- --strip (ref: src/dump1090.c:3423-3448): returns the bytes written to `out` (room for nbytes) ---- */
+size_t   orc_strip (const uint8_t *in, size_t nbytes, int level, uint64_t *run_io, uint8_t *out);
+
 size_t          orc_num_messages (const orc_ctx *c);
 const orc_msg  *orc_messages (const orc_ctx *c);
 void            orc_get_stats (const orc_ctx *c, orc_stats *out);

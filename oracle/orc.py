@@ -95,6 +95,8 @@ def lib():
         L.orc_icao_import.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_last_tail.argtypes = [C.c_void_p]
         L.orc_last_tail.restype = C.c_uint32
+        L.orc_strip.restype = C.c_size_t
+        L.orc_strip.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint64), C.c_void_p]
         L.orc_num_messages.restype = C.c_size_t
         L.orc_num_messages.argtypes = [C.c_void_p]
         L.orc_messages.restype = C.c_void_p
@@ -242,6 +244,15 @@ def convert(conv_id, iq, nsamples, sample_rate=2400000.0, filter_dc=False, state
     p = C.c_double(-1.0)
     L.orc_convert(conv_id, _ptr(iq), _ptr(mag), nsamples, C.byref(state), C.byref(p))
     return mag, p.value, state
+
+
+def strip(iq, level, run=0):
+    """strip_mode_loop (ref: src/dump1090.c:3423-3448) over a uint8 buffer; returns (kept bytes, counter carried out)."""
+    a = np.ascontiguousarray(iq, dtype=np.uint8)
+    out = np.zeros(a.size + 2, dtype=np.uint8)
+    r = C.c_uint64(run)
+    n = lib().orc_strip(_ptr(a), a.size, int(level), C.byref(r), _ptr(out))
+    return out[:n].copy(), int(r.value)
 
 
 def crc_checksum(msg, bits):

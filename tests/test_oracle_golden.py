@@ -154,3 +154,18 @@ def test_frames_js_manchester_slicer():
                 assert orc.crc_checksum(m[:7], 56) & 0xFFFF80 == 0
     assert tot["Decoded with good CRC"] == 108 and hit["Decoded with good CRC"] == 106
     assert hit["Demodulated with 0 errors"] == 86
+
+
+def test_strip_fixed_point_modes1(modes1):
+    """testfiles/modes1.bin was made with `--strip 25` (README.md:482-489): the sequential loop of
+    ref src/dump1090.c:3423-3448 must give it back unchanged at that level -- with runs of exactly 32 quiet pairs
+    present, which pins "the 33rd is the first one dropped" -- and shorten it at a higher level."""
+    out, _ = orc.strip(modes1, 25)
+    assert np.array_equal(out, modes1)
+    I, Q = modes1[0::2].astype(int), modes1[1::2].astype(int)
+    q = (abs(I - 127) < 25) & (abs(Q - 127) < 25)
+    x = np.diff(np.concatenate([[0], q.astype(int), [0]]))
+    runs = np.flatnonzero(x == -1) - np.flatnonzero(x == 1)
+    assert runs.max() == 32 and (runs == 32).sum() > 1000
+    out30, _ = orc.strip(modes1, 30)
+    assert out30.size < modes1.size
