@@ -50,6 +50,25 @@ class DcInfo(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
 
 
+class D8State(C.Structure):
+    """modes_d8_state: what demod_8000 carries from one shard of a recording to the next."""
+    _fields_ = [("acc", C.c_int32), ("acc_valid", C.c_int32), ("pending", C.c_int64), ("trig_tail", C.c_uint64),
+                ("amb_steps", C.c_uint64), ("dprev", C.c_int32 * 1928)]
+
+    def key(self):
+        """What must be equal for two hand-overs to be the same (amb_steps describes the run, not the state)."""
+        return (self.acc if self.acc_valid else None, self.pending, self.trig_tail, bytes(self.dprev))
+
+
+class PowerStats(C.Structure):
+    _fields_ = [("signal_power_sum", C.c_double), ("signal_power_count", C.c_uint64), ("peak_signal_power", C.c_double),
+                ("strong_signal_count", C.c_uint64), ("noise_power_sum", C.c_double), ("noise_power_count", C.c_uint64),
+                ("noise_valid", C.c_int32), ("reserved", C.c_int32)]
+
+    def asdict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+
+
 class ConvertState(C.Structure):
     _fields_ = [("DC_A", C.c_float), ("DC_B", C.c_float), ("z1_I", C.c_float), ("z1_Q", C.c_float),
                 ("func_name", C.c_char_p), ("description", C.c_char_p)]
@@ -120,6 +139,11 @@ def lib():
         L.modes_engine_run_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64]
         L.modes_engine_time_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
                                              C.POINTER(C.c_float)]
+        L.modes_engine_rerun_accept.argtypes = [C.c_void_p, C.c_void_p]
+        L.modes_engine_get_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.modes_engine_get_power_stats.argtypes = [C.c_void_p, C.POINTER(PowerStats)]
+        L.modes_engine_set_d8_state.argtypes = [C.c_void_p, C.POINTER(D8State)]
+        L.modes_engine_get_d8_state.argtypes = [C.c_void_p, C.POINTER(D8State), C.c_int, C.c_void_p]
         L.modes_engine_num_messages.restype = C.c_size_t
         L.modes_engine_num_messages.argtypes = [C.c_void_p]
         L.modes_engine_messages.restype = C.c_void_p
@@ -209,6 +233,28 @@ class Engine:
         _check(self.L.modes_engine_run_device(self.h, C.c_void_p(data_ptr), nbytes, first_sample,
                                               C.c_void_p(halo_ptr) if halo_ptr else None,
                                               C.c_void_p(stream) if stream else None))
+
+    def rerun_accept(self, stream=None):
+        """Repeat only the ordered accept pass + emit of the last run (after set_icao)."""
+        _check(self.L.modes_engine_rerun_accept(self.h, C.c_void_p(stream) if stream else None))
+
+    def counters(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        _check(self.L.modes_engine_get_counters(self.h, C.byref(a), C.byref(b)))
+        return {"scan_launches": int(a.value), "accept_passes": int(b.value)}
+
+    def power_stats(self):
+        s = PowerStats()
+        _check(self.L.modes_engine_get_power_stats(self.h, C.byref(s)))
+        return s.asdict()
+
+    def set_d8_state(self, state):
+        _check(self.L.modes_engine_set_d8_state(self.h, C.byref(state) if state is not None else None))
+
+    def get_d8_state(self, want_acc=False, stream=None):
+        s = D8State()
+        _check(self.L.modes_engine_get_d8_state(self.h, C.byref(s), int(want_acc), C.c_void_p(stream) if stream else None))
+        return s
 
     def run_host(self, iq, first_sample=0):
         iq = np.ascontiguousarray(iq)

@@ -151,6 +151,7 @@ struct modes_engine {
   DevBuf<uint64_t> chunk_sum, chunk_vp, chunk_ovf, packed_pos, offsets, rssi_pos, rssi_sum, vp_bitmap;
   DevBuf<uint8_t> staging;                  // for run_host
   DevBuf<uint16_t> tail;
+  uint32_t tail_half = 0;                   // which half of `tail` the last run wrote
   DevBuf<double> block_power;
   DevBuf<uint32_t> noise_level;
   size_t nblocks_power = 0;
@@ -203,6 +204,20 @@ struct modes_engine {
   unsigned long long *pin_small = nullptr;   // 32 words: totals and statistics read back once per round; word 32: `changed`
   uint32_t *pin_cache = nullptr;             // the ICAO cache behind the last block, read back with them
   modes_stats stats;
+  // what modes_engine_rerun_accept() needs: the last scan's geometry (its records are still in `records`)
+  ScanParams last_sp;
+  uint64_t last_first_sample = 0;
+  bool have_scan = false;
+  uint64_t scan_launches = 0, accept_passes = 0;      // since the engine was created
+  // 8 MS/s: state carried in from the shard before (one run), and what this run leaves for the next
+  modes_d8_state d8_in, d8_out;
+  bool d8_in_set = false, d8_out_acc_valid = false;
+  DevBuf<int32_t> d8_dprev, d8_dnext;
+  PinBuf<int32_t> pin_d8;
+  uint64_t d8_amb_steps = 0, d8_limit = 0;
+  unsigned long long d8_trig_tail_in = 0;
+  D8Params d8_q;
+  bool d8_have_run = false, d8_passthrough = false;
 };
 
 namespace {
@@ -548,6 +563,7 @@ int run_accept_on_device (modes_engine *e, const ScanParams &sp, uint64_t first_
     if (rounds > 256) return fail (MODES_E_HIP, "accept pass did not reach its fixed point in 256 rounds");
   }
   e->stats.replay_rounds = rounds;
+  e->accept_passes++;
   memcpy (e->cache.raw (), e->pin_cache, kIcaoSlots * sizeof (uint32_t));
   (void) hipEventElapsedTime (&e->kernel_ms[0], e->ev[0], e->ev[1]);
   e->kernel_ms[1] = 0;
@@ -656,7 +672,7 @@ int modes_engine_create (const modes_engine_config *cfg, modes_engine **out)
   }
   int rc = setup_tables (e);
   if (rc != MODES_OK) { modes_engine_destroy (e); return rc; }
-  rc = e->tail.reserve (e->ov);
+  rc = e->tail.reserve (2 * size_t (e->ov) + 16);       // two halves: a run writes the one the previous run did not (its halo may be that one)
   if (rc != MODES_OK) { modes_engine_destroy (e); return rc; }
   for (hipEvent_t &ev : e->ev)
     if (hipEventCreate (&ev) != hipSuccess) { modes_engine_destroy (e); return fail (MODES_E_HIP, "hipEventCreate failed"); }
@@ -682,6 +698,7 @@ void modes_engine_destroy (modes_engine *e)
   e->d8_win_count.release (); e->d8_chunk_rec.release (); e->d8_announce.release (); e->d8_table.release (); e->d8_entry.release ();
   e->d8_win_start.release (); e->d8_small.release (); e->d8_windows.release (); e->d8_win_packed.release ();
   e->d8_records.release (); e->d8_rec_packed.release (); e->dirty.release (); e->pin_chunks.release ();
+  e->d8_dprev.release (); e->d8_dnext.release (); e->pin_d8.release ();
   if (e->copy_stream) (void) hipStreamDestroy (e->copy_stream);
   for (hipEvent_t ev : e->emit_events) if (ev) (void) hipEventDestroy (ev);
   e->pin_wins.release (); e->pin_recs.release (); e->pin_bits.release (); e->pin_counts.release ();
@@ -726,6 +743,7 @@ static int run_device_inner (modes_engine *e, const void *d_iq, size_t nbytes, u
   HIP_TRY (hipSetDevice (e->cfg.device));
   e->messages.clear ();
   e->in_pinned = false; e->pin_n = 0;
+  e->have_scan = false;
   memset (&e->stats, 0, sizeof e->stats);
 
   ScanParams sp;
@@ -737,6 +755,15 @@ static int run_device_inner (modes_engine *e, const void *d_iq, size_t nbytes, u
   // slots (up to one per position and retry kind) until everything fits.
   const uint32_t cap_max = e->mode == 2000 ? 3u * kStrip : uint32_t (kStrip);
   std::vector<uint32_t> cache_in (e->cache.raw (), e->cache.raw () + kIcaoSlots);      // an overflowed attempt may have touched it
+  e->tail_half ^= 1;                        // once per run: a rescan writes the same half again
+  e->nblocks_power = 0;
+  if (e->mode == 2400 && e->cfg.compute_power && !e->cfg.filter_dc && !e->cfg.mode_ac) {
+    // Modes.measure_noise: demod_2400 reads mag_buf.mean_power of every block (ref: src/demod-2400.c:524-530)
+    const uint32_t nblocks = uint32_t ((sp.nsamples + e->block_samples - 1) / e->block_samples);
+    if ((rc = e->block_power.reserve (nblocks)) != MODES_OK) return rc;
+    HIP_TRY (launch_block_power (sp, nblocks, e->block_power.p, stream));
+    e->nblocks_power = nblocks;
+  }
   for (;;) {
     rc = scan_and_decode (e, sp, first_sample, stream);
     if (rc != MODES_E_OVERFLOW || e->cap >= cap_max) return rc;
@@ -758,8 +785,9 @@ static int scan_and_decode (modes_engine *e, ScanParams &sp, uint64_t first_samp
   int rc;
   HIP_TRY (hipEventRecord (e->ev[0], stream));
   HIP_TRY (e->mode == 2000 ? launch_scan2000 (sp, stream) : launch_scan2400 (sp, stream));
+  e->scan_launches++;
   HIP_TRY (hipEventRecord (e->ev[1], stream));
-  HIP_TRY (launch_tail (sp, sp.nsamples, e->tail.p, stream));        // what a following shard needs as d_halo
+  HIP_TRY (launch_tail (sp, sp.nsamples, e->tail.p + e->tail_half * ((e->ov + 7u) & ~7u), stream));   // what a following shard needs as d_halo
 
   // totals, then compact the per-strip slots into one ordered list
   const uint32_t nchunks = (sp.nstrips + 1023) / 1024;
@@ -770,8 +798,11 @@ static int scan_and_decode (modes_engine *e, ScanParams &sp, uint64_t first_samp
   uint64_t *d_totals = reinterpret_cast<uint64_t *> (e->d_stats);
   HIP_TRY (launch_count_scan (e->counts.p, e->vp_counts.p, sp.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p,
                               d_totals, stream));
-  if (!e->cfg.host_replay && !e->cfg.phase_enhance)
-    return run_accept_on_device (e, sp, first_sample, stream);
+  if (!e->cfg.host_replay && !e->cfg.phase_enhance) {
+    rc = run_accept_on_device (e, sp, first_sample, stream);
+    if (rc == MODES_OK) { e->last_sp = sp; e->last_first_sample = first_sample; e->have_scan = true; }
+    return rc;
+  }
 
   unsigned long long st[3];
   HIP_TRY (hipMemcpyAsync (st, d_totals, sizeof st, hipMemcpyDeviceToHost, stream));
@@ -941,7 +972,29 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   q.T = T; q.nsteps = T / 8;
   q.bshift = 0; while ((1u << q.bshift) < B) q.bshift++;
   q.acc0 = 0; q.pending = 1;
-  if (q.nsteps == 0) return MODES_OK;
+  // what the shard before left (ref: src/demod-8000.c:80-89,186-220): one run only
+  const bool have_in = e->d8_in_set;
+  e->d8_in_set = false;
+  e->d8_out_acc_valid = false;
+  e->d8_amb_steps = 0;
+  e->d8_have_run = false;
+  unsigned long long trig_tail_in = 0;
+  if (first_sample != 0 && !have_in)
+    return fail (MODES_E_ARG, "demod_8000: a shard that does not start the stream needs modes_engine_set_d8_state() from the shard before it");
+  if (have_in) {
+    int rc_in;
+    if ((rc_in = e->d8_dprev.reserve (kD8Overlap)) != MODES_OK) return rc_in;
+    HIP_TRY (hipMemcpyAsync (e->d8_dprev.p, e->d8_in.dprev, kD8Overlap * sizeof (int32_t), hipMemcpyHostToDevice, stream));
+    q.dprev = e->d8_dprev.p;
+    q.acc0 = e->d8_in.acc; q.pending = e->d8_in.pending; trig_tail_in = e->d8_in.trig_tail;
+  }
+  e->tail_half ^= 1;
+  HIP_TRY (launch_tail (sp, sp.nsamples, e->tail.p + e->tail_half * ((e->ov + 7u) & ~7u), stream));   // what a following shard needs as d_halo
+  if (q.nsteps == 0) {
+    if (have_in) { e->d8_out = e->d8_in; e->d8_out_acc_valid = e->d8_in.acc_valid != 0; e->d8_have_run = true; e->d8_passthrough = true; }
+    return MODES_OK;
+  }
+  e->d8_passthrough = false;
   const uint32_t nchunks = uint32_t ((q.nsteps + kD8ChunkSteps - 1) / kD8ChunkSteps);
   q.nchunks = nchunks;
   const size_t nwords = size_t (q.nsteps / 64 + 64);
@@ -976,6 +1029,9 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   unsigned long long limit = 0;
   HIP_TRY (hipMemcpyAsync (&limit, d_limit, sizeof limit, hipMemcpyDeviceToHost, stream));
   HIP_TRY (hipStreamSynchronize (stream));
+  if (limit && have_in && !e->d8_in.acc_valid)
+    return fail (MODES_E_ARG, "demod_8000: this shard holds steps whose trigger depends on the running average (near-silent input): "
+                              "the state handed over must carry acc (modes_engine_get_d8_state with want_acc)");
   if (limit) {
     // some steps sit in the band where the trigger depends on the running average: form it, in order, up to the last one
     if ((rc = e->d8_p0.reserve (size_t (q.nsteps) + 64)) != MODES_OK) return rc;
@@ -1000,7 +1056,21 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
       HIP_TRY (launch_d8_seed (q.announce, e->small_u32.p, nseed, stream));
     }
   }
-  HIP_TRY (launch_d8_chain (q, 0ull, 0ll, d_pre, d_pending, stream));
+  HIP_TRY (launch_d8_chain (q, trig_tail_in, 0ll, d_pre, d_pending, stream));
+  {
+    // what this run leaves for the shard behind it: the last 1928 differences, the open window, the last 64 trigger
+    // decisions (read back with the first range's counts below); acc only on request (modes_engine_get_d8_state)
+    int rc_out;
+    if ((rc_out = e->d8_dnext.reserve (kD8Overlap)) != MODES_OK) return rc_out;
+    if ((rc_out = e->pin_d8.reserve (kD8Overlap + 16)) != MODES_OK) return rc_out;
+    HIP_TRY (launch_d8_tail (q, e->d8_dnext.p, stream));
+    HIP_TRY (hipMemcpyAsync (e->pin_d8.p, e->d8_dnext.p, kD8Overlap * sizeof (int32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY (hipMemcpyAsync (e->pin_d8.p + kD8Overlap, d_pending, sizeof (long long), hipMemcpyDeviceToHost, stream));
+    const size_t w_last = size_t ((q.nsteps - 1) >> 6);
+    HIP_TRY (hipMemcpyAsync (e->pin_d8.p + kD8Overlap + 2, q.trig + (w_last ? w_last - 1 : 0), (w_last ? 2 : 1) * sizeof (uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY (hipMemcpyAsync (e->pin_d8.p + kD8Overlap + 6, q.amb_count, sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
+  }
+  e->d8_q = q; e->d8_limit = limit; e->d8_trig_tail_in = trig_tail_in;
   // The completed windows in up to four ranges of chunks.  While the host walks one range's records in order (the
   // part of demod_8000 that needs the live ICAO cache), the device works on the next range: the queue is
   //   windows(0) count(0) | gather(0) copy(0) windows(1) count(1) | gather(1) copy(1) windows(2) ...
@@ -1075,6 +1145,29 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
       }, ps);
     host_ms += std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - t_host0).count ();
   }
+  {
+    // the hand-over state (the copies were queued in front of the first range: long done)
+    modes_d8_state &o = e->d8_out;
+    memcpy (o.dprev, e->pin_d8.p, kD8Overlap * sizeof (int32_t));
+    long long pend; memcpy (&pend, e->pin_d8.p + kD8Overlap, sizeof pend);
+    o.pending = pend;
+    uint64_t tw[2] = { 0, 0 };
+    const size_t w_last = size_t ((q.nsteps - 1) >> 6);
+    if (w_last) memcpy (tw, e->pin_d8.p + kD8Overlap + 2, 2 * sizeof (uint64_t)); else memcpy (&tw[1], e->pin_d8.p + kD8Overlap + 2, sizeof (uint64_t));
+    uint64_t tail = 0;
+    for (int b = 0; b < 64; b++) {
+      const long long n = (long long) q.nsteps - 64 + b;               // step of bit b
+      bool bit;
+      if (n >= 0) { const size_t wi = size_t (n) >> 6; bit = (tw[wi == w_last ? 1 : 0] >> (n & 63)) & 1; }
+      else bit = (n + 64 >= 0) ? ((trig_tail_in >> (n + 64)) & 1) : false;   // still a step of the shard before
+      if (bit) tail |= 1ull << b;
+    }
+    o.trig_tail = tail;
+    uint32_t namb; memcpy (&namb, e->pin_d8.p + kD8Overlap + 6, sizeof namb);
+    o.amb_steps = namb; e->d8_amb_steps = namb;
+    o.acc = 0; o.acc_valid = 0;
+    e->d8_have_run = true;
+  }
   if (getenv ("MODES_TIMING")) fprintf (stderr, "run_8000: ordered pass %.3f ms in %u ranges, %zu messages\n", host_ms, nranges, e->messages.size ());
   e->stats.valid_preamble = ps.valid_preamble; e->stats.demodulated = ps.demodulated;
   e->stats.CRC_good = ps.CRC_good; e->stats.CRC_bad = ps.CRC_bad; e->stats.CRC_single_bit_fix = ps.CRC_single_bit_fix;
@@ -1108,6 +1201,110 @@ int modes_engine_run_device (modes_engine *e, const void *d_iq, size_t nbytes, u
   if (rc == MODES_OK && e->mode == 2400 && e->cfg.mode_ac)
     rc = run_mode_ac_2400 (e, d_iq, nbytes, first_sample, d_halo, static_cast<hipStream_t> (stream_v));
   return rc;
+}
+
+// The scan's records do not depend on the ICAO cache: a shard whose entry cache changed (the hand-over rounds of a
+// sharded decode) only repeats the ordered pass and the emit.
+int modes_engine_rerun_accept (modes_engine *e, void *stream_v)
+{
+  if (!e) return fail (MODES_E_ARG, "null engine");
+  if (!e->have_scan || e->cfg.mode_ac)
+    return fail (MODES_E_ARG, "modes_engine_rerun_accept: no scan to repeat the accept pass on (needs a successful 2.0 / 2.4 MS/s run "
+                              "with the ordered pass on the device and without mode_ac)");
+  HIP_TRY (hipSetDevice (e->cfg.device));
+  hipStream_t stream = static_cast<hipStream_t> (stream_v);
+  const uint64_t retries = e->stats.scan_retries, cand = e->stats.candidates;
+  e->messages.clear ();
+  e->in_pinned = false; e->pin_n = 0;
+  memset (&e->stats, 0, sizeof e->stats);
+  e->stats.scan_retries = retries;
+  // the totals of the scan are formed again from the per-strip counts (run_accept_on_device reads them with its own)
+  uint64_t *d_totals = reinterpret_cast<uint64_t *> (e->d_stats);
+  HIP_TRY (launch_count_scan (e->counts.p, e->vp_counts.p, e->last_sp.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p, d_totals, stream));
+  (void) cand;
+  return run_accept_on_device (e, e->last_sp, e->last_first_sample, stream);
+}
+
+int modes_engine_set_d8_state (modes_engine *e, const modes_d8_state *in)
+{
+  if (!e) return fail (MODES_E_ARG, "null engine");
+  if (e->mode != 8000) return fail (MODES_E_ARG, "modes_engine_set_d8_state: not an 8 MS/s engine");
+  if (!in) { e->d8_in_set = false; return MODES_OK; }
+  if (in->pending >= 0 && in->pending != 1) return fail (MODES_E_ARG, "modes_d8_state.pending must be < 0, or 1 for none");
+  e->d8_in = *in;
+  e->d8_in_set = true;
+  return MODES_OK;
+}
+
+int modes_engine_get_d8_state (modes_engine *e, modes_d8_state *out, int want_acc, void *stream_v)
+{
+  if (!e || !out) return fail (MODES_E_ARG, "null argument");
+  if (e->mode != 8000 || !e->d8_have_run) return fail (MODES_E_ARG, "modes_engine_get_d8_state: no 8 MS/s run to read the state of");
+  hipStream_t stream = static_cast<hipStream_t> (stream_v);
+  if (want_acc && !e->d8_out_acc_valid && !e->d8_passthrough) {
+    // d8m_phase_av_acc behind the last step: the recurrence over every step of the shard (ref: src/demod-8000.c:275-288)
+    HIP_TRY (hipSetDevice (e->cfg.device));
+    D8Params q = e->d8_q;
+    int rc;
+    if ((rc = e->d8_p0.reserve (size_t (q.nsteps) + 64)) != MODES_OK) return rc;
+    if ((rc = e->d8_mx.reserve (size_t (q.nsteps) + 64)) != MODES_OK) return rc;
+    q.p0 = e->d8_p0.p; q.mx = e->d8_mx.p; q.write_arrays = 1;
+    // d8_trig_kernel counts ambiguous steps into amb_count and rewrites the trigger words without the decisions the
+    // running average added: both are restored by the acc kernel walking the whole shard (it ORs the same bits back)
+    if (e->d8_limit < q.nsteps) HIP_TRY (launch_d8_trig (q, 0, stream));
+    int32_t *d_acc = reinterpret_cast<int32_t *> (e->d8_small.p + 7);
+    HIP_TRY (launch_d8_acc (q, q.nsteps, d_acc, stream));
+    int32_t acc = 0;
+    HIP_TRY (hipMemcpyAsync (&acc, d_acc, sizeof acc, hipMemcpyDeviceToHost, stream));
+    HIP_TRY (hipStreamSynchronize (stream));
+    e->d8_out.acc = acc; e->d8_out.acc_valid = 1;
+    e->d8_out_acc_valid = true;
+  }
+  *out = e->d8_out;
+  return MODES_OK;
+}
+
+int modes_engine_get_counters (const modes_engine *e, uint64_t *scan_launches, uint64_t *accept_passes)
+{
+  if (!e) return fail (MODES_E_ARG, "null engine");
+  if (scan_launches) *scan_launches = e->scan_launches;
+  if (accept_passes) *accept_passes = e->accept_passes;
+  return MODES_OK;
+}
+
+// ref: src/demod-2400.c:498-505,524-530 (only demod_2400 keeps these)
+int modes_engine_get_power_stats (modes_engine *e, modes_power_stats *out)
+{
+  if (!e || !out) return fail (MODES_E_ARG, "null argument");
+  memset (out, 0, sizeof *out);
+  if (e->mode != 2400) return MODES_OK;
+  const size_t n = modes_engine_num_messages (e);
+  const modes_message *m = modes_engine_messages (e);
+  const uint32_t B = e->block_samples, blk0 = uint32_t (e->last_first_sample / B);
+  std::vector<double> blk_signal;                 // sum of the signal powers of a block's messages, in message order
+  for (size_t i = 0; i < n; i++) {
+    if (m[i].msg_type == 32) continue;            // Mode A/C replies come from demod_2400_AC
+    const int slen = int (m[i].msg_bits) * 12 / 5;
+    const double signal_power = m[i].sig_level * slen;
+    out->signal_power_sum += signal_power;
+    out->signal_power_count += uint64_t (slen);
+    if (m[i].sig_level > out->peak_signal_power) out->peak_signal_power = m[i].sig_level;
+    if (m[i].sig_level > 0.50119) out->strong_signal_count++;
+    const size_t b = m[i].block >= blk0 ? m[i].block - blk0 : 0;
+    if (blk_signal.size () <= b) blk_signal.resize (b + 1, 0.0);
+    blk_signal[b] += signal_power;
+  }
+  if (e->cfg.compute_power && e->nblocks_power) {     // Modes.measure_noise: mean_power of every block was formed with the run
+    std::vector<double> pw (e->nblocks_power);
+    HIP_TRY (hipSetDevice (e->cfg.device));
+    HIP_TRY (hipMemcpy (pw.data (), e->block_power.p, pw.size () * sizeof (double), hipMemcpyDeviceToHost));
+    for (size_t b = 0; b < pw.size (); b++) {
+      out->noise_power_sum += pw[b] - (b < blk_signal.size () ? blk_signal[b] : 0.0);
+      out->noise_power_count += uint64_t (B) + e->ov;                       // mag->total_length: the buffer's capacity
+    }
+    out->noise_valid = 1;
+  }
+  return MODES_OK;
 }
 
 int modes_engine_run_host (modes_engine *e, const void *iq, size_t nbytes, uint64_t first_sample)
@@ -1217,7 +1414,7 @@ size_t modes_engine_block_power (modes_engine *e, double *out, size_t max)
   return n;
 }
 
-const uint16_t *modes_engine_tail_halo (const modes_engine *e) { return e ? e->tail.p : nullptr; }
+const uint16_t *modes_engine_tail_halo (const modes_engine *e) { return e ? e->tail.p + e->tail_half * ((e->ov + 7u) & ~7u) : nullptr; }
 
 int modes_engine_set_dc_state (modes_engine *e, float z1_I, float z1_Q)
 {

@@ -1,12 +1,22 @@
 """Sharding one long recording over several GPUs (ref: src/infile.c:116-197).
 
 A recording is cut into contiguous ranges of whole 256 KiB blocks, one range per rank.  What a shard needs from the
-stream before it: (a) the `overlap` magnitudes in front of its first sample -- a pure function of the samples, each
-rank forms them itself -- and (b) the 1024-slot ICAO cache at its first block, which depends on every message before
-it.  (b) is resolved the way the blocks inside a shard are: decode with a guess, exchange the caches the shards end
-with (4 KiB each), decode again with the neighbour's exit cache, stop when no entry cache changes.  Decisions only depend
+stream before it:
+
+  (a) the `overlap` magnitudes in front of its first sample -- a pure function of the samples, each rank forms them
+      itself from the few samples it holds in front of its shard (`modes_engine_halo_at`);
+  (b) the 1024-slot ICAO cache at its first block, which depends on every message before it;
+  (c) at 8 MS/s, what demod_8000 carries between calls (ref: src/demod-8000.c:80-89): the last 1928 differences (a pure
+      function of the previous shard's samples), the match window still open and the trigger history (which depend on
+      where the window chain stood when it entered the previous shard), and the running average (only read by shards
+      with near-silent stretches, only formed when one of them asks).
+
+(b) and (c) are resolved the way the blocks inside a shard are: decode with a guess, exchange what the shards end with
+(a few KiB each), decode again from the neighbour's exit state, stop when no entry state changes.  Decisions only depend
 on earlier positions, so the fixed point is the sequential result; it is reached after at most `world` rounds, in
-practice two.  No data-path collective: only the caches and the (small) message lists travel.
+practice two.  At 2.0 / 2.4 MS/s the scan kernel's records do not depend on the cache, so rounds after the first
+repeat only the ordered accept pass (`modes_engine_rerun_accept`).  No data-path collective: only the states and
+the (small) message lists travel.
 """
 import numpy as np
 
@@ -31,21 +41,37 @@ class LocalGroup:
         self.world = world
 
 
-def decode_sharded(decode, rank, world, all_gather, initial_icao=None, max_rounds=None):
-    """Runs `decode(entry_icao) -> (messages, exit_icao)` for this rank's shard until the entry caches of all ranks
-    are consistent.  `all_gather(obj) -> [obj of rank 0, ...]`.  Returns (messages of this shard, rounds)."""
-    entry = np.zeros(1024, dtype=np.uint32) if initial_icao is None or rank > 0 else np.asarray(initial_icao, dtype=np.uint32)
+def _same(a, b):
+    if isinstance(a, dict):
+        return a.keys() == b.keys() and all(_same(a[k], b[k]) for k in a)
+    if isinstance(a, np.ndarray) or isinstance(b, np.ndarray):
+        return np.array_equal(a, b)
+    return a == b
+
+
+def decode_sharded(decode, rank, world, all_gather, initial_icao=None, max_rounds=None, initial_state=None):
+    """Runs `decode(entry_state) -> (messages, exit_state)` for this rank's shard until the entry states of all ranks
+    are consistent.  A state is the ICAO cache (uint32[1024]) or a dict of named parts (compared part by part).
+    `all_gather(obj) -> [obj of rank 0, ...]`.  A rank whose entry state did not change keeps its result.
+    Returns (messages of this shard, rounds)."""
+    if initial_state is not None:
+        entry = initial_state
+    else:
+        entry = np.zeros(1024, dtype=np.uint32) if initial_icao is None or rank > 0 else np.asarray(initial_icao, dtype=np.uint32)
     rounds = 0
+    msgs = exit_state = None
+    fresh = True
     while True:
-        msgs, exit_icao = decode(entry)
+        if fresh:
+            msgs, exit_state = decode(entry)
         rounds += 1
-        exits = all_gather(np.asarray(exit_icao, dtype=np.uint32))
-        new_entry = entry if rank == 0 else np.asarray(exits[rank - 1], dtype=np.uint32)
-        changed = bool(np.any(new_entry != entry))
-        if not any(all_gather(changed)):
+        exits = all_gather(exit_state)
+        new_entry = entry if rank == 0 else exits[rank - 1]
+        fresh = not _same(new_entry, entry)
+        if not any(all_gather(fresh)):
             return msgs, rounds
         if max_rounds is not None and rounds >= max_rounds:
-            raise RuntimeError("ICAO hand-over did not settle in %d rounds" % rounds)
+            raise RuntimeError("state hand-over did not settle in %d rounds" % rounds)
         entry = new_entry
 
 
@@ -53,3 +79,129 @@ def merge(per_rank_messages):
     """Shards are consecutive in time, so the merged list is their concatenation in rank order."""
     parts = [m for m in per_rank_messages if len(m)]
     return np.concatenate(parts) if parts else per_rank_messages[0][:0]
+
+
+class ThreadGroup:
+    """all_gather between `world` threads of one process (tests, and hosts that drive several GPUs from one process)."""
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.slots = [None] * world
+        self.barrier = threading.Barrier(world)
+
+    def all_gather(self, rank):
+        def gather(obj):
+            self.slots[rank] = obj
+            self.barrier.wait()
+            out = list(self.slots)
+            self.barrier.wait()
+            return out
+        return gather
+
+
+class EngineShard:
+    """One rank's shard of a recording behind a `dump1090_amd.Engine`: `decode` is what `decode_sharded` calls.
+
+    The rank holds bytes [buf_ptr, buf_ptr + buf_nbytes) of the stream in device memory: `lead_samples` samples in
+    front of its shard (whole blocks; one block for every rank but the first -- the overlap magnitudes in front of the
+    shard are formed from them) and then the shard's `count` samples, which start at stream sample `first_sample`.
+    The state handed from shard to shard is {"icao": uint32[1024]} plus, at 8 MS/s, {"d8": bytes of modes_d8_state}."""
+
+    def __init__(self, engine, buf_ptr, buf_nbytes, lead_samples, first_sample, count, sample_rate, bytes_per_sample, stream=None):
+        import torch
+        self.e, self.first, self.count = engine, first_sample, count
+        self.buf_ptr, self.buf_nbytes, self.lead = buf_ptr, buf_nbytes, lead_samples
+        self.rate, self.bps, self.stream = sample_rate, bytes_per_sample, stream
+        self.ptr = buf_ptr + lead_samples * bytes_per_sample
+        self.ov = int((8 + 112 + 16) * 1e-6 * sample_rate)          # ref: src/dump1090.c:734
+        block = 262144 // bytes_per_sample
+        if lead_samples % block or (first_sample and lead_samples < block):
+            raise ValueError("the lead-in must be whole blocks, one at least for a shard behind the stream's start")
+        self.halo = torch.zeros(self.ov + 8, dtype=torch.int16, device="cuda") if first_sample else None
+        self.scanned = False
+        self.rounds = 0
+        self.amb_steps = 0
+
+    def initial_state(self):
+        st = {"icao": np.zeros(1024, dtype=np.uint32)}
+        if self.rate == 8000000:
+            from . import D8State
+            z = D8State()
+            z.pending, z.acc_valid = 1, 1                            # a guess for round one: nothing carried in
+            st["d8"] = bytes(z)
+        return st
+
+    def decode(self, entry):
+        from . import D8State
+        e = self.e
+        self.rounds += 1
+        e.set_icao(entry["icao"])
+        if self.rate != 8000000 and self.scanned and self.count:
+            e.rerun_accept(stream=self.stream)                       # the scan's records do not depend on the cache
+        else:
+            halo = None
+            if self.first:
+                # the magnitudes in front of the shard, from the block the rank holds in front of it
+                e.halo_at(self.buf_ptr, self.buf_nbytes, self.lead, self.halo.data_ptr(), stream=self.stream)
+                halo = self.halo.data_ptr()
+            if self.rate == 8000000 and self.first:
+                e.set_d8_state(D8State.from_buffer_copy(entry["d8"]))
+            e.run_device(self.ptr, self.count * self.bps, first_sample=self.first, halo_ptr=halo, stream=self.stream)
+            self.scanned = True
+        out = {"icao": e.get_icao()}
+        if self.rate == 8000000:
+            out["d8"] = self._d8_exit(entry)
+        return e.messages(), out
+
+    def _d8_exit(self, entry):
+        from . import D8State
+        if self.count == 0:
+            return entry["d8"]
+        s = self.e.get_d8_state(want_acc=False, stream=self.stream)
+        self.amb_steps = int(s.amb_steps)
+        s.amb_steps = 0                                              # describes the run, not the state handed on
+        s.acc, s.acc_valid = 0, 1                                    # acc travels only on request: see exit_with_acc()
+        return bytes(s)
+
+    def exit_with_acc(self, exit_state):
+        """The same exit state with the running average formed (a walk over every step of the shard)."""
+        from . import D8State
+        if self.count == 0:
+            return exit_state
+        s = self.e.get_d8_state(want_acc=True, stream=self.stream)
+        s.amb_steps = 0
+        out = dict(exit_state)
+        out["d8"] = bytes(s)
+        return out
+
+
+def decode_engine_sharded(shard, rank, world, all_gather, max_rounds=None):
+    """decode_sharded over an EngineShard, with the one extra rule of the 8 MS/s path: when some shard holds steps whose
+    trigger depends on demod_8000's running average, every shard forms and hands on that average too."""
+    need_acc = [False]
+
+    def decode(entry):
+        msgs, out = shard.decode(entry)
+        if shard.rate == 8000000:
+            amb = any(all_gather(bool(getattr(shard, "amb_steps", 0))))
+            if amb or need_acc[0]:
+                need_acc[0] = True
+                out = shard.exit_with_acc(out)
+        return msgs, out
+
+    if shard.rate != 8000000:
+        return decode_sharded(shard.decode, rank, world, all_gather, max_rounds=max_rounds, initial_state=shard.initial_state())
+    # 8 MS/s: every rank decodes in every round (the all_gather inside `decode` must be entered by all)
+    entry = shard.initial_state()
+    rounds = 0
+    while True:
+        msgs, exit_state = decode(entry)
+        rounds += 1
+        exits = all_gather(exit_state)
+        new_entry = entry if rank == 0 else exits[rank - 1]
+        changed = not _same(new_entry, entry)
+        if not any(all_gather(changed)):
+            return msgs, rounds
+        if max_rounds is not None and rounds >= max_rounds:
+            raise RuntimeError("state hand-over did not settle in %d rounds" % rounds)
+        entry = new_entry

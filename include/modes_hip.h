@@ -230,6 +230,49 @@ int  modes_engine_kernel_ms (const modes_engine *e, float *main_ms, float *secon
  * *text points into host memory owned by the engine (valid until the next call), NUL-terminated. */
 int  modes_engine_format_raw (modes_engine *e, int upper_case, const char **text, size_t *len);
 
+/* Sharded decodes hand the ICAO cache from shard to shard and repeat until no entry cache changes.  What the scan
+ * kernel found does not depend on the cache: after modes_engine_set_icao() this repeats only the ordered accept pass
+ * and the emit of the LAST run (2.0 / 2.4 MS/s, ordered pass on the device, no mode_ac; the run's d_iq must still be
+ * valid: the signal level is read from it).  Results replace those of the last run. */
+int  modes_engine_rerun_accept (modes_engine *e, void *stream);
+/* scan kernel launches and ordered passes since the engine was created */
+int  modes_engine_get_counters (const modes_engine *e, uint64_t *scan_launches, uint64_t *accept_passes);
+
+/* Modes.stat.signal_power_* / peak_signal_power / strong_signal_count / noise_power_* as demod_2400 keeps them
+ * (ref: src/demod-2400.c:498-505,524-530), for the last run.  The noise figures need mag_buf.mean_power of every block:
+ * they are formed when compute_power is set (Modes.measure_noise) and the converter is not a DC-filter one
+ * (noise_valid = 0 otherwise).  Floats agree with the reference within 1e-12 relative (sums of doubles in message order). */
+typedef struct modes_power_stats {
+  double   signal_power_sum;
+  uint64_t signal_power_count;
+  double   peak_signal_power;
+  uint64_t strong_signal_count;
+  double   noise_power_sum;
+  uint64_t noise_power_count;
+  int32_t  noise_valid, reserved;
+} modes_power_stats;
+int  modes_engine_get_power_stats (modes_engine *e, modes_power_stats *out);
+
+/* ---- demod_8000: what the reference keeps in file-static variables between calls (ref: src/demod-8000.c:80-89,
+ * 186-220,509-522), for shards of one 8 MS/s recording.  A run that does not start the stream (first_sample != 0) must
+ * be given the state the shard before it left; modes_engine_get_d8_state() reads what the last run leaves behind.
+ *   acc         d8m_phase_av_acc.  Forming it means walking every step of the shard in order, so it is only done on
+ *               request (want_acc); a shard only reads it if it holds steps whose trigger depends on the running
+ *               average (amb_steps != 0 after its run: near-silent input).
+ *   pending     step (< 0, relative to the next shard's first step) at which a match window still open was opened; 1 = none
+ *   trig_tail   trigger decisions of the last 64 steps (the search resumes 55 steps before a window's end)
+ *   dprev       the last 1928 four-sample differences (d8m_dbuf's overlap)                                        */
+typedef struct modes_d8_state {
+  int32_t  acc;
+  int32_t  acc_valid;        /* out: acc was formed; in: 0 = unknown (fails with MODES_E_ARG if the shard needs it) */
+  int64_t  pending;
+  uint64_t trig_tail;
+  uint64_t amb_steps;        /* out only: steps of the last run whose trigger depended on the running average */
+  int32_t  dprev[1928];
+} modes_d8_state;
+int  modes_engine_set_d8_state (modes_engine *e, const modes_d8_state *in);      /* applies to the next run only */
+int  modes_engine_get_d8_state (modes_engine *e, modes_d8_state *out, int want_acc, void *stream);
+
 size_t               modes_engine_num_messages (const modes_engine *e);
 const modes_message *modes_engine_messages (const modes_engine *e);      /* host memory */
 int                  modes_engine_get_stats (const modes_engine *e, modes_stats *out);

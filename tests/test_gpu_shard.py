@@ -58,3 +58,120 @@ def test_tail_halo_chains_shards_sequentially():
         parts.append(e.messages())
         halo = e.tail_halo()                          # same engine: its ICAO cache carries over by itself
     assert_same_messages(shard.merge(parts), exp)
+
+
+def _capture_8000(nblocks=7, extra=321, quiet=False, seed=94):
+    """sc16 at 8 MS/s: regular traffic plus one frame laid around every block edge, so that shard seams fall inside
+    open match windows.  `quiet`: noise of a dozen LSB, where demod_8000's trigger depends on its running average."""
+    rng = np.random.default_rng(seed)
+    B = 65536
+    n = B * nblocks + extra
+    x, _ = synth.capture_complex(n, 8e6, seed + 1, frames_per_sec=1200, ap_fraction=0.3, n_icao=6,
+                                 noise_sigma=0.0004 if quiet else 0.01, min_amp_db=-40 if quiet else -32,
+                                 max_amp_db=-25 if quiet else -4)
+    offs = (-1500, -1200, -960, -700, -400, -130, -20, 0, 90)
+    for b in range(1, nblocks):
+        p = b * B + offs[(b * 4) % len(offs)]
+        msg = synth.make_df17(0x4840D6 + b, bytes(rng.integers(0, 256, 7, dtype=np.uint8)))
+        env = synth.envelope(msg, 8e6, rng.random())
+        x[p - 200:p + len(env) + 200] *= 0.05                      # clear the regular traffic around it
+        x[p:p + len(env)] += (0.03 if quiet else 0.3) * np.exp(2j * np.pi * rng.random()) * env
+    return synth.quantise(x, "sc16")
+
+
+@pytest.mark.parametrize("quiet", [False, True])
+def test_8000_shards_chain_sequentially(quiet):
+    """demod_8000 shards of one recording, each given the state the shard before left (acc, open window, trigger
+    history, 1928 differences) + its tail halo: the three shards together = the oracle's single pass.  `quiet`: input
+    so weak that triggers depend on the running average, which then has to travel too."""
+    iq = _capture_8000(quiet=quiet)
+    exp, _ = oracle_run(iq, "sc16", rate=8000000)
+    assert len(exp) > 40
+    d = torch.from_numpy(iq).to("cuda:0")
+    single = da.Engine(8000000, da.INPUT_SC16, fix_bits=1)
+    single.run_device(d.data_ptr(), iq.nbytes)
+    assert_same_messages(single.messages(), exp)
+    e = da.Engine(8000000, da.INPUT_SC16, fix_bits=1)
+    parts, halo, state = [], None, None
+    seam_windows = 0
+    for first, count in shard.plan_shards(len(iq) // 2, 65536, 3):
+        if state is not None:
+            e.set_d8_state(state)
+        e.run_device(d.data_ptr() + 4 * first, 4 * count, first_sample=first, halo_ptr=halo)
+        parts.append(e.messages())
+        halo = e.tail_halo()
+        state = e.get_d8_state(want_acc=True)
+        seam_windows += state.pending < 0
+        if quiet:
+            assert state.amb_steps > 0
+    assert_same_messages(shard.merge(parts), exp)
+    assert seam_windows >= 1 or quiet                  # a shard ended inside an open match window
+
+    # a shard in the middle of the stream without the state of the one before is refused, not guessed
+    first, count = shard.plan_shards(len(iq) // 2, 65536, 3)[1]
+    with pytest.raises(da.ModesError):
+        e.run_device(d.data_ptr() + 4 * first, 4 * count, first_sample=first)
+
+
+def _run_ranks(world, make_shard):
+    """`world` threads, one EngineShard each, through shard.decode_engine_sharded (what bench.py runs rank per GPU)."""
+    import threading
+    grp = shard.ThreadGroup(world)
+    out = [None] * world
+    err = []
+
+    def work(r):
+        try:
+            sh = make_shard(r)
+            msgs, rounds = shard.decode_engine_sharded(sh, r, world, grp.all_gather(r), max_rounds=world + 2)
+            out[r] = (msgs, rounds, sh)
+        except BaseException as ex:                   # noqa: BLE001
+            err.append(ex)
+            grp.barrier.abort()
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if err:
+        raise err[0]
+    return out
+
+
+@pytest.mark.parametrize("rate,fmt,world", [(2400000, "sc16", 3), (2000000, "sc16", 2), (2400000, "uc8lut", 2), (8000000, "sc16", 3),
+                                            (8000000, "quiet", 3)])
+def test_engine_shards_reach_the_single_pass_result(rate, fmt, world):
+    """The product path of a sharded decode: every rank holds only its shard and one block in front of it, forms its
+    own halo, and the entry states (ICAO cache; at 8 MS/s also demod_8000's carried state) are handed over until they
+    settle.  From the second round on no scan kernel runs at 2.0 / 2.4 MS/s."""
+    if rate == 8000000:
+        iq = _capture_8000(nblocks=9, quiet=fmt == "quiet")
+        efmt, bps, ofmt = da.INPUT_SC16, 4, "sc16"
+    elif fmt == "uc8lut":
+        iq, _ = synth.capture_lut_image(131072 * 7 + 999, 2.4e6, seed=96, frames_per_sec=3000, min_amp_db=-22, ap_fraction=0.5, n_icao=6)
+        efmt, bps, ofmt = da.INPUT_UC8, 2, "uc8"
+    else:
+        iq, _ = synth.capture(65536 * 9 + 4321, float(rate), "sc16", seed=92, frames_per_sec=2500, ap_fraction=0.5, n_icao=6, bitflip1=0.2)
+        efmt, bps, ofmt = da.INPUT_SC16, 4, "sc16"
+    exp, _ = oracle_run(iq, ofmt, rate=rate)
+    B = 262144 // bps
+    raw = np.ascontiguousarray(iq).view(np.uint8)
+    plan = shard.plan_shards(raw.size // bps, B, world)
+    held = []
+
+    def make_shard(r):
+        first, count = plan[r]
+        lead = B if first else 0
+        buf = torch.from_numpy(raw[(first - lead) * bps:(first + count) * bps].copy()).to("cuda:0")     # all this rank ever sees
+        held.append(buf)
+        return shard.EngineShard(da.Engine(rate, efmt, fix_bits=1), buf.data_ptr(), buf.numel(), lead, first, count, rate, bps)
+    res = _run_ranks(world, make_shard)
+    got = shard.merge([m for m, _, _ in res])
+    assert_same_messages(got, exp)
+    assert len(exp) > 40
+    rounds = res[0][1]
+    assert 2 <= rounds <= world + 1
+    for _, _, sh in res:
+        c = sh.e.counters()
+        if rate != 8000000:
+            assert c["scan_launches"] == 1 and c["accept_passes"] == sh.rounds    # later rounds: the ordered pass only
