@@ -12,12 +12,25 @@ pytestmark = pytest.mark.gpu
 FMT = {"uc8": da.INPUT_UC8, "sc16": da.INPUT_SC16, "sc16q11": da.INPUT_SC16Q11}
 
 
+def assert_power_stats(e, est, noise):
+    """Modes.stat.signal_power_* / noise_power_* (ref: src/demod-2400.c:498-505,524-530)."""
+    ps = e.power_stats()
+    assert ps["signal_power_count"] == est["signal_power_count"] and ps["strong_signal_count"] == est["strong_signal_count"]
+    np.testing.assert_allclose(ps["signal_power_sum"], est["signal_power_sum"], rtol=1e-9)
+    np.testing.assert_allclose(ps["peak_signal_power"], est["peak_signal_power"], rtol=1e-12)
+    assert ps["noise_valid"] == int(noise)
+    if noise:
+        assert ps["noise_power_count"] == est["noise_power_count"]
+        np.testing.assert_allclose(ps["noise_power_sum"], est["noise_power_sum"], rtol=1e-9)
+
+
 def engine_run(iq, fmt, **kw):
     """Runs the engine twice -- ordered accept pass on the device (default) and on the host -- and checks
     that both give the same messages and statistics before handing them to the oracle comparison."""
     e = da.Engine(2400000, FMT[fmt], **kw)
     e.run_host(iq)
     got, st = e.messages(), e.stats()
+    engine_run.last = e
     h = da.Engine(2400000, FMT[fmt], host_replay=True, **kw)
     h.run_host(iq)
     got_h, st_h = h.messages(), h.stats()
@@ -90,6 +103,7 @@ def test_uc8_lut_image_messages_match_oracle(compute_power):
     sent = {f["clean"] for f in frames}
     back = sum(1 for g in got if bytes(g["msg"][: int(g["msg_bits"]) // 8]) in sent)
     assert back > 0.7 * len(frames)
+    assert_power_stats(engine_run.last, est, noise=compute_power)
 
 
 def test_uc8_lut_image_frames_on_block_seams():
@@ -120,6 +134,7 @@ def test_sc16_generic_power_path_matches_oracle():
     assert len(exp) > 200
     assert_same_messages(got, exp)
     assert gst["valid_preamble"] == est["valid_preamble"]
+    assert_power_stats(engine_run.last, est, noise=True)
 
 
 def test_sc16q11_matches_oracle():
