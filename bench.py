@@ -5,6 +5,12 @@ One "step" = one pass of the whole hot path (IQ resident in HBM -> ordered messa
 over one synthetic recording (or, for the Mode A/C batch, over the rank's recordings back to back).
 Prints ONE JSON line on rank 0.
 
+N > 1 (one rank per GPU): ONE recording of N x --gib is cut into N shards of whole 256 KiB blocks (dump1090_amd/shard.py).
+Every rank holds its shard plus one block in front of it, forms its own overlap magnitudes, and the entry states (ICAO
+cache; at 8 MS/s demod_8000's carried state) are handed from shard to shard until they settle -- all inside the timed
+step.  Per-GPU work is fixed as N grows ("scaling": "weak").  The float converters with the DC block on and the
+Mode A/C batch run as independent recordings per rank.
+
 Workloads (BASELINE.json `configs`):
   uc8_2400      configs[1]  synthetic 2.4 MS/s uc8, 4 GiB, DF11/DF17 at mixed SNR        (default, the headline)
   uc8_2400_lut              the headline's kernel instance on an input it decodes: a uc8 buffer whose image under the
@@ -101,14 +107,31 @@ def run_workload(name, args, world, rank, local, dev, want_cpu):
         nrec = 1
         nsamples = int(args.gib * (1 << 30)) // bps
     fmt_id = da.INPUT_UC8 if fmt == "uc8" else da.INPUT_SC16
+    sharded = world > 1 and nrec == 1 and not dc
     t0 = time.time()
     recs = []
-    for r in range(nrec):
-        iq, info = synth_torch.capture_gpu(nsamples, float(rate), gen_fmt, seed=1 + rank * 64 + r, device=dev, **traffic)
+    lead = 0
+    if sharded:
+        # this rank's part of ONE recording of world x nsamples: its shard and the block in front of it
+        from dump1090_amd import shard as shard_mod
+        B = 262144 // bps
+        plan = shard_mod.plan_shards(world * nsamples, B, world)
+        first, count = plan[rank]
+        chunk = 1 << 24
+        lead = B if first else 0
+        g0 = (first - lead) // chunk * chunk
+        iq_all, info = synth_torch.capture_gpu(world * nsamples, float(rate), gen_fmt, seed=1, device=dev, chunk=chunk,
+                                               sample_range=(g0, -(-(first + count) // chunk) * chunk), **traffic)
+        iq = iq_all[2 * (first - lead - g0): 2 * (first + count - g0)]
+        info = dict(info, pos=info["pos"][(info["pos"] >= first) & (info["pos"] < first + count)])
         recs.append((iq, info))
+    else:
+        for r in range(nrec):
+            iq, info = synth_torch.capture_gpu(nsamples, float(rate), gen_fmt, seed=1 + rank * 64 + r, device=dev, **traffic)
+            recs.append((iq, info))
     torch.cuda.synchronize()
     gen_s = time.time() - t0
-    nbytes = recs[0][0].numel() * recs[0][0].element_size()
+    nbytes = recs[0][0].numel() * recs[0][0].element_size() - lead * bps
     eng = da.Engine(rate, fmt_id, device=local, **dict(ekw, compute_power=power))
     stream = torch.cuda.current_stream().cuda_stream
     # a batch of independent recordings (configs[4]) is decoded by several engines at once, each on its own HIP stream
@@ -129,6 +152,20 @@ def run_workload(name, args, world, rank, local, dev, want_cpu):
             dist.barrier()
         torch.cuda.synchronize()
 
+    sh = grp = None
+    hand_rounds = [0]
+    if sharded:
+        iq = recs[0][0]
+        sh = shard_mod.EngineShard(eng, iq.data_ptr(), iq.numel() * iq.element_size(), lead, first, count, rate, bps, stream=stream)
+        grp = shard_mod.TorchGroup(args.coll_dev)
+
+    def run_sharded():
+        sh.reset()
+        rounds = shard_mod.decode_engine_rounds(sh, rank, world, grp.all_gather, max_rounds=2 * world + 2)
+        hand_rounds[0] = rounds
+        a, b = eng.kernel_ms()
+        return eng.num_messages(), a, b
+
     def run_lane(li):
         e, st = lanes[li][0], lanes[li][1]
         nm, kms, k2 = 0, 0.0, 0.0
@@ -146,6 +183,8 @@ def run_workload(name, args, world, rank, local, dev, want_cpu):
         return nm, kms, k2
 
     def one_step():
+        if sharded:
+            return run_sharded()
         if pool is None:
             return run_lane(0)
         parts = list(pool.map(run_lane, range(nlanes)))
@@ -164,17 +203,41 @@ def run_workload(name, args, world, rank, local, dev, want_cpu):
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=args.coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     last_eng = lanes[(nrec - 1) % nlanes][0]          # the engine that decoded recs[-1] last
     msgs = last_eng.messages()
     stats = last_eng.stats()
-    nmsg = torch.tensor([nm], device=dev, dtype=torch.int64)
+    nmsg = torch.tensor([nm], device=args.coll_dev, dtype=torch.int64)
     if world > 1:
         dist.all_reduce(nmsg)
     step_s = dt / args.steps
     value = world * nrec * nsamples / step_s / 1e6               # Msamples/s, whole job
+    shard_info = None
+    if sharded:
+        # outside the timed region: the shards' lists gathered on rank 0 (rank order = time order) and checked
+        t0 = time.perf_counter()
+        cdev = args.coll_dev
+        raw = torch.from_numpy(msgs.view(np.uint8).reshape(-1).copy()).to(cdev) if len(msgs) else torch.zeros(0, dtype=torch.uint8, device=cdev)
+        sizes = grp.all_gather(np.array([raw.numel()], dtype=np.int64))
+        cap_b = max(int(x[0]) for x in sizes)
+        pad = torch.zeros(max(cap_b, 1), dtype=torch.uint8, device=cdev)
+        pad[: raw.numel()] = raw
+        allb = torch.empty(world * pad.numel(), dtype=torch.uint8, device=cdev)
+        dist.all_gather_into_tensor(allb, pad)
+        merged_n, ordered = 0, True
+        if rank == 0:
+            host = allb.cpu().numpy().reshape(world, -1)
+            parts = [np.frombuffer(host[r, : int(sizes[r][0])].tobytes(), dtype=da.MESSAGE_DTYPE) for r in range(world)]
+            merged = shard_mod.merge(parts)
+            merged_n = int(len(merged))
+            ordered = bool(np.all(np.diff(merged["timestamp"].astype(np.int64)) >= -2700))      # skip-ahead keeps messages apart
+        shard_info = {"recording_gib": round(world * nsamples * bps / (1 << 30), 2), "shards": world, "handover_rounds": hand_rounds[0],
+                      "merged_msgs_on_rank0": merged_n, "merged_in_time_order": ordered,
+                      "gather_to_rank0_ms": round((time.perf_counter() - t0) * 1e3, 2),
+                      "note": "timed step = scan + hand-over rounds + each shard's ordered list in its rank's host memory; "
+                              "the gather of the lists to rank 0 is measured here, outside it"}
 
     # dominant kernel: HIP events on the launch stream around it, averaged over the timed steps
     kernel_ms = kms / args.steps / nrec                           # per launch
@@ -278,14 +341,15 @@ def run_workload(name, args, world, rank, local, dev, want_cpu):
             else "%s IQ" % fmt)
     return {
         "value": round(value, 1), "ms_per_step": round(step_s * 1e3, 3),
-        "config": {"workload": "%s: synthetic %.1f MS/s %s, %d x %.2f GiB per GPU, injected DF11/DF17 frames at mixed SNR"
-                               % (name, rate / 1e6, what, nrec, nbytes / (1 << 30)),
+        "config": {"workload": ("%s: synthetic %.1f MS/s %s, %d x %.2f GiB per GPU, injected DF11/DF17 frames at mixed SNR"
+                                % (name, rate / 1e6, what, nrec, nbytes / (1 << 30)))
+                               + (", ONE %.0f GiB recording sharded over %d GPUs" % (world * nbytes / (1 << 30), world) if sharded else ""),
                    "converter": conv_name, "demod": "demod_%d%s" % (rate // 1000, "+demod_2400_AC" if ekw.get("mode_ac") else ""),
                    "fix_bits": ekw.get("fix_bits", 1), "frames_injected_per_gpu": int(sum(len(i["pos"]) for _, i in recs)),
                    "concurrent_engines": nlanes},
         "msgs": int(nmsg.item()), "msgs_per_s": round(int(nmsg.item()) / step_s, 1),
         "valid_preamble": stats["valid_preamble"], "candidates": stats["candidates"],
-        "roofline": roofline, "cpu_baseline": cpu, "gen_seconds": round(gen_s, 1)}
+        "roofline": roofline, "cpu_baseline": cpu, "gen_seconds": round(gen_s, 1), "shard": shard_info}
 
 
 def main():
@@ -309,11 +373,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # MODES_BENCH_REHEARSE=1: all ranks on GPU 0 with gloo collectives, to rehearse the N > 1 path on a one-GPU box
+    rehearse = bool(os.environ.get("MODES_BENCH_REHEARSE"))
+    if rehearse:
+        local = 0
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
+    args.coll_dev = "cpu" if rehearse else dev
 
     res = run_workload(args.workload, args, world, rank, local, dev, want_cpu=(rank == 0 and world == 1 and not args.no_cpu))
     also = None
@@ -338,6 +410,8 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic"}
         out.update({k: res[k] for k in ("config", "msgs", "msgs_per_s", "valid_preamble", "candidates", "roofline",
                                         "cpu_baseline", "gen_seconds")})
+        if res.get("shard"):
+            out["shard"] = res["shard"]
         if also:
             out["also"] = also
         print(json.dumps(out))

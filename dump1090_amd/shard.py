@@ -99,6 +99,42 @@ class ThreadGroup:
         return gather
 
 
+class TorchGroup:
+    """all_gather over torch.distributed (one process per GPU; backend "nccl" is RCCL on ROCm, "gloo" on CPU).  The
+    hand-over states are a few KiB: they travel as one fixed-size byte tensor per rank, flags as one int."""
+    D8_BYTES = 4 + 4 + 8 + 8 + 8 + 4 * 1928
+
+    def __init__(self, device):
+        import torch.distributed as dist
+        self.dist, self.device = dist, device
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+
+    def _gather_bytes(self, blob):
+        import torch
+        t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(self.device)
+        out = torch.empty(self.world * t.numel(), dtype=torch.uint8, device=self.device)
+        self.dist.all_gather_into_tensor(out, t)
+        return out.cpu().numpy().reshape(self.world, -1)
+
+    def all_gather(self, obj):
+        if isinstance(obj, (bool, np.bool_)):
+            return [bool(r[0]) for r in self._gather_bytes(bytes([int(obj)]))]
+        if isinstance(obj, dict):
+            blob = np.asarray(obj["icao"], dtype=np.uint32).tobytes() + obj.get("d8", b"")
+            rows = self._gather_bytes(blob)
+            out = []
+            for r in rows:
+                st = {"icao": np.frombuffer(r[:4096].tobytes(), dtype=np.uint32).copy()}
+                if "d8" in obj:
+                    st["d8"] = r[4096:4096 + self.D8_BYTES].tobytes()
+                out.append(st)
+            return out
+        if isinstance(obj, np.ndarray):
+            rows = self._gather_bytes(np.ascontiguousarray(obj).tobytes())
+            return [np.frombuffer(r.tobytes(), dtype=obj.dtype).reshape(obj.shape).copy() for r in rows]
+        raise TypeError("TorchGroup.all_gather: %r" % type(obj))
+
+
 class EngineShard:
     """One rank's shard of a recording behind a `dump1090_amd.Engine`: `decode` is what `decode_sharded` calls.
 
@@ -118,6 +154,10 @@ class EngineShard:
         if lead_samples % block or (first_sample and lead_samples < block):
             raise ValueError("the lead-in must be whole blocks, one at least for a shard behind the stream's start")
         self.halo = torch.zeros(self.ov + 8, dtype=torch.int16, device="cuda") if first_sample else None
+        self.reset()
+
+    def reset(self):
+        """Forget the last decode (a new pass over the shard scans again)."""
         self.scanned = False
         self.rounds = 0
         self.amb_steps = 0
@@ -151,7 +191,10 @@ class EngineShard:
         out = {"icao": e.get_icao()}
         if self.rate == 8000000:
             out["d8"] = self._d8_exit(entry)
-        return e.messages(), out
+        return None, out                                             # the list stays in the engine: messages() fetches it
+
+    def messages(self):
+        return self.e.messages()
 
     def _d8_exit(self, entry):
         from . import D8State
@@ -176,32 +219,41 @@ class EngineShard:
 
 
 def decode_engine_sharded(shard, rank, world, all_gather, max_rounds=None):
-    """decode_sharded over an EngineShard, with the one extra rule of the 8 MS/s path: when some shard holds steps whose
-    trigger depends on demod_8000's running average, every shard forms and hands on that average too."""
-    need_acc = [False]
+    """decode_engine_rounds, then this shard's messages.  Returns (messages of this shard, rounds)."""
+    rounds = decode_engine_rounds(shard, rank, world, all_gather, max_rounds)
+    return shard.messages(), rounds
 
-    def decode(entry):
-        msgs, out = shard.decode(entry)
-        if shard.rate == 8000000:
-            amb = any(all_gather(bool(getattr(shard, "amb_steps", 0))))
-            if amb or need_acc[0]:
-                need_acc[0] = True
-                out = shard.exit_with_acc(out)
-        return msgs, out
 
+def decode_engine_rounds(shard, rank, world, all_gather, max_rounds=None):
+    """decode_sharded over an EngineShard; the list stays in the shard's engine.  Returns the number of rounds.
+
+    One extra rule at 8 MS/s: when a shard behind the first holds steps whose trigger depends on demod_8000's running
+    average (near-silent input), every shard forms that average and hands it on as well.  The first round does not
+    count for this: its entry states are guesses (no differences carried in looks like silence)."""
     if shard.rate != 8000000:
-        return decode_sharded(shard.decode, rank, world, all_gather, max_rounds=max_rounds, initial_state=shard.initial_state())
-    # 8 MS/s: every rank decodes in every round (the all_gather inside `decode` must be entered by all)
+        _, rounds = decode_sharded(shard.decode, rank, world, all_gather, max_rounds=max_rounds, initial_state=shard.initial_state())
+        return rounds
+    # every rank enters every collective of a round; a rank whose entry state did not change keeps its result
     entry = shard.initial_state()
+    need_acc = with_acc = False
+    fresh = True
     rounds = 0
     while True:
-        msgs, exit_state = decode(entry)
+        if fresh:
+            _, exit_state = shard.decode(entry)
+            with_acc = False
         rounds += 1
+        flags = all_gather(bool(shard.amb_steps) and rank > 0 and rounds > 1)
+        if any(flags):
+            need_acc = True
+        if need_acc and not with_acc:
+            exit_state = shard.exit_with_acc(exit_state)
+            with_acc = True
         exits = all_gather(exit_state)
         new_entry = entry if rank == 0 else exits[rank - 1]
-        changed = not _same(new_entry, entry)
-        if not any(all_gather(changed)):
-            return msgs, rounds
+        fresh = not _same(new_entry, entry)
+        if not any(all_gather(fresh)):
+            return rounds
         if max_rounds is not None and rounds >= max_rounds:
             raise RuntimeError("state hand-over did not settle in %d rounds" % rounds)
         entry = new_entry

@@ -27,11 +27,13 @@ def _bank(rng, sample_rate, n_bank, n_icao, df17_fraction):
 
 def capture_gpu(nsamples, sample_rate=2.4e6, fmt="uc8", seed=1, frames_per_sec=1000.0, device="cuda:0",
                 noise_sigma=0.01, n_icao=64, n_bank=4096, overlap_fraction=0.1, df17_fraction=0.6,
-                min_amp_db=-32.0, max_amp_db=-4.0, dc_offset=(0.0, 0.0), chunk=1 << 24):
+                min_amp_db=-32.0, max_amp_db=-4.0, dc_offset=(0.0, 0.0), chunk=1 << 24, sample_range=None):
     """Returns (iq tensor on `device`: uint8[2n] or int16[2n], dict with frame positions / bank indices).
     fmt "uc8lut": a uc8 buffer whose image under the reference's as-written byte table is the signal's envelope
     (synth.capture_lut_image): byte = round(|x| * 128) in the first half of every 256 KiB block, random bytes in the
-    half the converter never reads."""
+    half the converter never reads.
+    sample_range = (a, b), multiples of `chunk`: only samples [a, b) of the recording are generated (every chunk has
+    its own noise seed, so any rank can form its part of one long recording); the tensor then holds 2 (b - a) values."""
     rng = np.random.default_rng(seed)
     bank, msgs = _bank(rng, sample_rate, n_bank, n_icao, df17_fraction)
     L = bank.shape[1]
@@ -55,15 +57,20 @@ def capture_gpu(nsamples, sample_rate=2.4e6, fmt="uc8", seed=1, frames_per_sec=1
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
     bank_t = torch.from_numpy(bank).to(dev)
-    out = torch.empty(2 * nsamples, dtype=torch.uint8 if fmt in ("uc8", "uc8lut") else torch.int16, device=dev)
+    r0, r1 = (0, nsamples) if sample_range is None else (max(0, sample_range[0]), min(nsamples, sample_range[1]))
+    assert r0 % chunk == 0 and (r1 % chunk == 0 or r1 == nsamples), "sample_range must lie on the chunk grid"
+    whole = out = torch.empty(2 * (r1 - r0), dtype=torch.uint8 if fmt in ("uc8", "uc8lut") else torch.int16, device=dev)
     if fmt == "uc8lut":
         B = synth.LUT_BLOCK_SAMPLES
         assert chunk % B == 0
-        out.random_(0, 256, generator=gen)
     ar = torch.arange(L, device=dev)
-    for c0 in range(0, nsamples, chunk):
+    for c0 in range(r0, r1, chunk):
         c1 = min(c0 + chunk, nsamples)
         n = c1 - c0
+        gen.manual_seed(seed * 1000003 + c0 // chunk)            # a chunk's noise does not depend on the chunks before it
+        out = whole[2 * (c0 - r0):]                              # this chunk's part: indices below are relative to r0
+        if fmt == "uc8lut":
+            out[: 2 * n].random_(0, 256, generator=gen)
         x = torch.randn(2, n + L, generator=gen, device=dev, dtype=torch.float32) * noise_sigma
         x[0] += dc_offset[0]
         x[1] += dc_offset[1]
@@ -84,9 +91,9 @@ def capture_gpu(nsamples, sample_rate=2.4e6, fmt="uc8", seed=1, frames_per_sec=1
             mb = torch.clamp(torch.round(torch.sqrt(x[0, :n] ** 2 + x[1, :n] ** 2) * 128.0), 0, 128).to(torch.uint8)
             nfull = n // B
             if nfull:
-                out[2 * c0: 2 * (c0 + nfull * B)].view(nfull, 2, B)[:, 0, :] = mb[: nfull * B].view(nfull, B)
+                out[: 2 * nfull * B].view(nfull, 2, B)[:, 0, :] = mb[: nfull * B].view(nfull, B)
             if n > nfull * B:
-                out[2 * (c0 + nfull * B): 2 * (c0 + nfull * B) + (n - nfull * B)] = mb[nfull * B:]
+                out[2 * nfull * B: 2 * nfull * B + (n - nfull * B)] = mb[nfull * B:]
             del x, mb
             continue
         iq = x[:, :n].t().contiguous().view(-1)                  # interleave I,Q
@@ -96,6 +103,6 @@ def capture_gpu(nsamples, sample_rate=2.4e6, fmt="uc8", seed=1, frames_per_sec=1
             q = torch.clamp(torch.round(iq * 32767.0), -32768, 32767).to(torch.int16)
         else:
             q = torch.clamp(torch.round(iq * 2047.0), -2048, 2047).to(torch.int16)
-        out[2 * c0:2 * c1] = q
+        out[: 2 * n] = q
         del x, iq, q
-    return out, {"pos": pos, "which": which, "msgs": msgs, "amp": amp}
+    return whole, {"pos": pos, "which": which, "msgs": msgs, "amp": amp}
