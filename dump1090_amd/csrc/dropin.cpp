@@ -56,6 +56,7 @@ struct DropIn {
   std::vector<modes_message> queue;
   uint32_t block_counter = 0;
   bool d8_allocated = false;
+  uint64_t scan_retries = 0;      // scans repeated with more candidate slots per strip
   // demod_8000: what the reference keeps in file-static variables between calls (ref: src/demod-8000.c:80-89)
   struct D8 {
     int32_t *dprev = nullptr, *dnext = nullptr;     // the last 1928 differences (d8m_dbuf's overlap)
@@ -233,12 +234,13 @@ bool scan_mag_buf (const mag_buf *mag, std::vector<Record> &recs, uint64_t *vp_t
   const uint32_t mlen = mag->valid_length - mag->overlap;
   const uint32_t nstrips = (mlen + kStrip - 1) / kStrip;
   const bool pe = g.bound && g.host.phase_enhance;
-  const uint32_t cap = mode == 2000 ? uint32_t (pe ? kCap2000PE : kCap2000) : pe ? 128 : 32;
+  uint32_t cap = mode == 2000 ? uint32_t (pe ? kCap2000PE : kCap2000) : pe ? 128 : 32;
+  if (const char *ev = getenv ("MODES_STRIP_SLOTS")) if (atoi (ev) > 0) cap = uint32_t (atoi (ev));   // test hook: start small, grow on demand
+  const uint32_t cap_max = mode == 2000 ? 3u * kStrip : uint32_t (kStrip);     // one slot per position (and retry kind)
   recs.clear ();
   *vp_total = 0;
   if (nstrips == 0) return true;
   if (!grow (g.d_mag, g.mag_cap, size_t (mag->valid_length) + 64)) return false;
-  if (!grow (g.d_rec, g.rec_cap, size_t (nstrips) * kCap2000PE)) return false;
   if (nstrips > g.strip_cap) {
     for (void *p : { (void *) g.d_counts, (void *) g.d_vp, (void *) g.d_bitmap }) if (p) (void) hipFree (p);
     g.d_counts = g.d_vp = nullptr; g.d_bitmap = nullptr; g.strip_cap = 0;
@@ -248,42 +250,51 @@ bool scan_mag_buf (const mag_buf *mag, std::vector<Record> &recs, uint64_t *vp_t
     g.strip_cap = nstrips;
   }
   HIP_OK (hipMemcpyAsync (g.d_mag, mag->data, size_t (mag->valid_length) * 2, hipMemcpyHostToDevice, nullptr));
-  ScanParams sp;
-  memset (&sp, 0, sizeof sp);
-  sp.iq = reinterpret_cast<const uint8_t *> (g.d_mag);
-  sp.nsamples = mlen;
-  sp.navail = mag->valid_length;
-  sp.ov = mag->overlap;
-  sp.block_samples = mlen ? mlen : 1;
-  sp.conv = kConvMagU16;
-  sp.phase_enhance = g.bound ? g.host.phase_enhance : 0;
-  sp.short_tab = g.d_short; sp.short_n = g.short_n; sp.long_tab = g.d_long; sp.long_n = g.long_n;
-  sp.bloom_short = g.d_bloom_short; sp.bloom_long = g.d_bloom_long;
-  sp.lut256 = g.d_lut;
-  sp.records = g.d_rec; sp.counts = g.d_counts; sp.vp_counts = g.d_vp; sp.cap = cap; sp.nstrips = nstrips;
-  sp.write_records = 1;
-  sp.vp_bitmap = g.d_bitmap;
-  sp.log10_lut = g.d_log10; sp.crc_table = g.d_crc_table;
-  sp.mode_ac = g.bound ? g.host.mode_AC : 0;
   if (mode == 24001) {
     if (!g.d_noise) HIP_OK (hipMalloc (reinterpret_cast<void **> (&g.d_noise), sizeof (uint32_t)));
     HIP_OK (hipMemcpyAsync (g.d_noise, &noise_level, sizeof noise_level, hipMemcpyHostToDevice, nullptr));
-    sp.noise_level = g.d_noise;
-    HIP_OK (launch_scanac2400 (sp, nullptr));
-  } else
-    HIP_OK (mode == 2000 ? launch_scan2000 (sp, nullptr) : launch_scan2400 (sp, nullptr));
+  }
   std::vector<uint32_t> counts (nstrips), vp (nstrips);
-  HIP_OK (hipMemcpyAsync (counts.data (), g.d_counts, nstrips * sizeof (uint32_t), hipMemcpyDeviceToHost, nullptr));
-  HIP_OK (hipMemcpyAsync (vp.data (), g.d_vp, nstrips * sizeof (uint32_t), hipMemcpyDeviceToHost, nullptr));
-  HIP_OK (hipStreamSynchronize (nullptr));
-  std::vector<Record> strip (cap);
-  for (uint32_t s = 0; s < nstrips; s++) {
-    *vp_total += vp[s];
-    if (counts[s] == 0xFFFFFFFFu) {
-      set_error (MODES_E_OVERFLOW, "strip %u overflowed its candidate slots", s);
+  // A strip that holds more candidates than its slots is reported, never cut short: scan again with four times the
+  // slots until everything fits (as the bulk engine does), so a dense or saturated block is not lost.
+  for (;;) {
+    if (!grow (g.d_rec, g.rec_cap, size_t (nstrips) * cap)) return false;
+    ScanParams sp;
+    memset (&sp, 0, sizeof sp);
+    sp.iq = reinterpret_cast<const uint8_t *> (g.d_mag);
+    sp.nsamples = mlen;
+    sp.navail = mag->valid_length;
+    sp.ov = mag->overlap;
+    sp.block_samples = mlen ? mlen : 1;
+    sp.conv = kConvMagU16;
+    sp.phase_enhance = g.bound ? g.host.phase_enhance : 0;
+    sp.short_tab = g.d_short; sp.short_n = g.short_n; sp.long_tab = g.d_long; sp.long_n = g.long_n;
+    sp.bloom_short = g.d_bloom_short; sp.bloom_long = g.d_bloom_long;
+    sp.lut256 = g.d_lut;
+    sp.records = g.d_rec; sp.counts = g.d_counts; sp.vp_counts = g.d_vp; sp.cap = cap; sp.nstrips = nstrips;
+    sp.write_records = 1;
+    sp.vp_bitmap = g.d_bitmap;
+    sp.log10_lut = g.d_log10; sp.crc_table = g.d_crc_table;
+    sp.mode_ac = g.bound ? g.host.mode_AC : 0;
+    if (mode == 24001) { sp.noise_level = g.d_noise; HIP_OK (launch_scanac2400 (sp, nullptr)); }
+    else HIP_OK (mode == 2000 ? launch_scan2000 (sp, nullptr) : launch_scan2400 (sp, nullptr));
+    HIP_OK (hipMemcpyAsync (counts.data (), g.d_counts, nstrips * sizeof (uint32_t), hipMemcpyDeviceToHost, nullptr));
+    HIP_OK (hipMemcpyAsync (vp.data (), g.d_vp, nstrips * sizeof (uint32_t), hipMemcpyDeviceToHost, nullptr));
+    HIP_OK (hipStreamSynchronize (nullptr));
+    bool overflow = false;
+    for (uint32_t s = 0; s < nstrips; s++) overflow = overflow || counts[s] == 0xFFFFFFFFu;
+    if (!overflow) break;
+    if (cap >= cap_max) {
+      set_error (MODES_E_OVERFLOW, "a strip overflowed %u candidate slots", cap);
       fprintf (stderr, "modes_hip: %s\n", modes_last_error ());
       return false;
     }
+    cap = cap * 4 < cap_max ? cap * 4 : cap_max;
+    g.scan_retries++;
+  }
+  std::vector<Record> strip (cap);
+  for (uint32_t s = 0; s < nstrips; s++) {
+    *vp_total += vp[s];
     if (!counts[s]) continue;
     HIP_OK (hipMemcpy (strip.data (), g.d_rec + size_t (s) * cap, counts[s] * sizeof (Record), hipMemcpyDeviceToHost));
     for (uint32_t k = 0; k < counts[s]; k++) {

@@ -560,7 +560,8 @@ int run_accept_on_device (modes_engine *e, const ScanParams &sp, uint64_t first_
     HIP_TRY (hipStreamSynchronize (stream));
     rounds++;
     if (!*pin_changed) break;
-    if (rounds > 256) return fail (MODES_E_HIP, "accept pass did not reach its fixed point in 256 rounds");
+    // a write set can only change because an earlier block's did: block k is final after round k + 1 at the latest
+    if (rounds > nblocks + 2) return fail (MODES_E_HIP, "accept pass did not reach its fixed point in %u rounds", rounds);
   }
   e->stats.replay_rounds = rounds;
   e->accept_passes++;
@@ -906,14 +907,22 @@ static int run_mode_ac_2400 (modes_engine *e, const void *d_iq, size_t nbytes, u
   e->nblocks_power = nblocks;
   HIP_TRY (launch_noise_level (e->block_power.p, nblocks, e->noise_level.p, stream));
   sp.noise_level = e->noise_level.p;
-  HIP_TRY (launch_scanac2400 (sp, stream));
   uint64_t *d_totals = reinterpret_cast<uint64_t *> (e->d_stats);
-  HIP_TRY (launch_count_scan (e->counts.p, e->vp_counts.p, sp.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p,
-                              d_totals, stream));
   unsigned long long st[3];
-  HIP_TRY (hipMemcpyAsync (st, d_totals, sizeof st, hipMemcpyDeviceToHost, stream));
-  HIP_TRY (hipStreamSynchronize (stream));
-  if (st[2]) return fail (MODES_E_OVERFLOW, "%llu strips overflowed their Mode A/C slots", st[2]);
+  for (;;) {                                   // as the Mode S scan: a strip out of slots means scanning again with more
+    HIP_TRY (launch_scanac2400 (sp, stream));
+    HIP_TRY (launch_count_scan (e->counts.p, e->vp_counts.p, sp.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p,
+                                d_totals, stream));
+    HIP_TRY (hipMemcpyAsync (st, d_totals, sizeof st, hipMemcpyDeviceToHost, stream));
+    HIP_TRY (hipStreamSynchronize (stream));
+    if (!st[2]) break;
+    if (sp.cap >= uint32_t (kStrip)) return fail (MODES_E_OVERFLOW, "%llu strips overflowed their Mode A/C slots", st[2]);
+    sp.cap = sp.cap * 4 < uint32_t (kStrip) ? sp.cap * 4 : uint32_t (kStrip);
+    e->cap = sp.cap;
+    e->stats.scan_retries++;
+    if ((rc = e->records.reserve (size_t (sp.nstrips) * sp.cap)) != MODES_OK) return rc;
+    sp.records = e->records.p;
+  }
   const size_t nrec = size_t (st[0]);
   if (!nrec) return MODES_OK;
   if ((rc = e->packed.reserve (nrec + 1)) != MODES_OK) return rc;

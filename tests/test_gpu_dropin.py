@@ -99,6 +99,14 @@ def test_demod_2400_per_block_builtin_rules():
     assert_same_messages(got, exp)
 
 
+def test_demod_2400_drop_in_rescans_when_a_strip_runs_out_of_slots(monkeypatch):
+    """Two candidate slots per strip overflow on any real signal: the drop-in scans again with more until everything
+    fits (as the bulk engine does); the block is not lost and the result is the oracle's."""
+    monkeypatch.setenv("MODES_STRIP_SLOTS", "2")
+    test_demod_2400_per_block_builtin_rules()
+    test_demod_2000_per_block_builtin_rules()
+
+
 def test_demod_2400_per_block_with_host_callbacks():
     """dump1090.c's side of the boundary played by the oracle: score / decode / user_message callbacks."""
     iq, _ = synth.capture(65536 * 2 + 777, 2.4e6, "sc16", seed=32, frames_per_sec=2500, bitflip1=0.3, bitflip2=0.1,

@@ -60,6 +60,13 @@ def test_drop_in_demod_2400_AC_matches_oracle(mean_power):
     assert_same_messages(got, exp)
 
 
+def test_mode_ac_rescans_when_a_strip_runs_out_of_slots(monkeypatch):
+    """MODES_STRIP_SLOTS=1: both the bulk A/C pass and the drop-in demod_2400_AC scan again with more slots."""
+    monkeypatch.setenv("MODES_STRIP_SLOTS", "1")
+    test_bulk_mode_s_then_mode_ac_per_block(False)
+    test_drop_in_demod_2400_AC_matches_oracle(1e-4)
+
+
 @pytest.mark.parametrize("power", [False, True])
 def test_bulk_mode_s_then_mode_ac_per_block(power):
     """demod_2400 then demod_2400_AC on every block, as BASELINE.json configs[4] asks."""
