@@ -144,6 +144,8 @@ def lib():
         L.modes_engine_get_power_stats.argtypes = [C.c_void_p, C.POINTER(PowerStats)]
         L.modes_engine_set_d8_state.argtypes = [C.c_void_p, C.POINTER(D8State)]
         L.modes_engine_get_d8_state.argtypes = [C.c_void_p, C.POINTER(D8State), C.c_int, C.c_void_p]
+        L.modes_engine_decode_fields.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p]
+        L.modes_decode_fields_host.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.modes_engine_num_messages.restype = C.c_size_t
         L.modes_engine_num_messages.argtypes = [C.c_void_p]
         L.modes_engine_messages.restype = C.c_void_p
@@ -233,6 +235,15 @@ class Engine:
         _check(self.L.modes_engine_run_device(self.h, C.c_void_p(data_ptr), nbytes, first_sample,
                                               C.c_void_p(halo_ptr) if halo_ptr else None,
                                               C.c_void_p(stream) if stream else None))
+
+    def decode_fields(self, stream=None):
+        """Field decode of the last run's messages (FIELDS_DTYPE array, message order)."""
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(self.L.modes_engine_decode_fields(self.h, C.byref(p), C.byref(n), C.c_void_p(stream) if stream else None))
+        if not n.value:
+            return np.zeros(0, dtype=FIELDS_DTYPE)
+        buf = (C.c_char * (n.value * FIELDS_DTYPE.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=FIELDS_DTYPE).copy()
 
     def rerun_accept(self, stream=None):
         """Repeat only the ordered accept pass + emit of the last run (after set_icao)."""
@@ -346,6 +357,24 @@ def strip_device(d_iq_ptr, nbytes, level, d_out_ptr, run=0, stream=None):
     _check(lib().modes_strip_device(C.c_void_p(d_iq_ptr), nbytes, int(level), C.byref(r), C.c_void_p(d_out_ptr), C.byref(n),
                                     C.c_void_p(stream) if stream else None))
     return int(n.value), int(r.value)
+
+
+FIELDS_DTYPE = np.dtype([("AC_flags", "<u4"), ("addr", "<u4"), ("category", "<u4"), ("addrtype", "<u2"), ("reliable", "u1"),
+                         ("unit", "u1"), ("capa", "i1"), ("IID", "u1"), ("ME_type", "i1"), ("ME_subtype", "i1"), ("cf", "i1"),
+                         ("reserved0", "i1"), ("nuc_p", "u1"), ("EW_dir", "u1"), ("NS_dir", "u1"), ("reserved1", "u1", (3,)),
+                         ("flight_status", "<i4"), ("identity", "<i4"), ("altitude", "<i4"), ("altitude_HAE", "<i4"),
+                         ("HAE_delta", "<i4"), ("raw_latitude", "<i4"), ("raw_longitude", "<i4"), ("EW_velocity", "<i4"),
+                         ("NS_velocity", "<i4"), ("vert_rate", "<i4"), ("pad", "<u4"), ("heading", "<f8"), ("velocity", "<f8"),
+                         ("flight", "S9"), ("ME", "u1", (7,)), ("MD", "u1", (10,)), ("reserved2", "u1", (6,))])
+assert FIELDS_DTYPE.itemsize == 120
+
+
+def decode_fields_host(msgs):
+    """modes_decode_fields_host(): field decode of a MESSAGE_DTYPE array on the device."""
+    m = np.ascontiguousarray(msgs, dtype=MESSAGE_DTYPE)
+    out = np.zeros(len(m), dtype=FIELDS_DTYPE)
+    _check(lib().modes_decode_fields_host(m.ctypes.data_as(C.c_void_p), len(m), out.ctypes.data_as(C.c_void_p)))
+    return out
 
 
 NOALLOC_MAX_SAMPLES = 262144

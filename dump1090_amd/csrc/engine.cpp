@@ -148,6 +148,8 @@ struct modes_engine {
   DevBuf<Record> records, packed;
   DevBuf<uint32_t> counts, vp_counts, rssi_len, snap_in, delta, chunk_last, chunk_entry, acc_counts, blk_stats, small_u32;
   DevBuf<modes_message> d_messages;
+  DevBuf<modes_fields> d_fields;
+  PinBuf<modes_fields> pin_fields;
   DevBuf<uint64_t> chunk_sum, chunk_vp, chunk_ovf, packed_pos, offsets, rssi_pos, rssi_sum, vp_bitmap;
   DevBuf<uint8_t> staging;                  // for run_host
   DevBuf<uint16_t> tail;
@@ -700,6 +702,7 @@ void modes_engine_destroy (modes_engine *e)
   e->d8_win_start.release (); e->d8_small.release (); e->d8_windows.release (); e->d8_win_packed.release ();
   e->d8_records.release (); e->d8_rec_packed.release (); e->dirty.release (); e->pin_chunks.release ();
   e->d8_dprev.release (); e->d8_dnext.release (); e->pin_d8.release ();
+  e->d_fields.release (); e->pin_fields.release ();
   if (e->copy_stream) (void) hipStreamDestroy (e->copy_stream);
   for (hipEvent_t ev : e->emit_events) if (ev) (void) hipEventDestroy (ev);
   e->pin_wins.release (); e->pin_recs.release (); e->pin_bits.release (); e->pin_counts.release ();
@@ -1395,6 +1398,51 @@ int modes_engine_format_raw (modes_engine *e, int upper_case, const char **text,
   e->pin_text[total] = 0;
   *text = e->pin_text; *len = size_t (total);
   return MODES_OK;
+}
+
+int modes_engine_decode_fields (modes_engine *e, const modes_fields **out, size_t *n_out, void *stream_v)
+{
+  if (!e || !out || !n_out) return fail (MODES_E_ARG, "null argument");
+  *out = nullptr; *n_out = 0;
+  const size_t n = modes_engine_num_messages (e);
+  if (!n) return MODES_OK;
+  if (n > 0xFFFFFFFFull) return fail (MODES_E_ARG, "too many messages");
+  HIP_TRY (hipSetDevice (e->cfg.device));
+  hipStream_t stream = static_cast<hipStream_t> (stream_v);
+  int rc;
+  if ((rc = e->d_messages.reserve (n)) != MODES_OK) return rc;
+  if ((rc = e->d_fields.reserve (n)) != MODES_OK) return rc;
+  if ((rc = e->pin_fields.reserve (n)) != MODES_OK) return rc;
+  if (!e->in_pinned)                       // the host-ordered paths hold their messages in host memory only
+    HIP_TRY (hipMemcpyAsync (e->d_messages.p, e->messages.data (), n * sizeof (modes_message), hipMemcpyHostToDevice, stream));
+  HIP_TRY (launch_fields (e->d_messages.p, uint32_t (n), e->d_fields.p, stream));
+  HIP_TRY (hipMemcpyAsync (e->pin_fields.p, e->d_fields.p, n * sizeof (modes_fields), hipMemcpyDeviceToHost, stream));
+  HIP_TRY (hipStreamSynchronize (stream));
+  *out = e->pin_fields.p; *n_out = n;
+  return MODES_OK;
+}
+
+// the same kernel on a caller's list (messages that did not come from a run: RAW / SBS input, replays)
+int modes_decode_fields_host (const modes_message *msgs, size_t n, modes_fields *out)
+{
+  if ((!msgs || !out) && n) return fail (MODES_E_ARG, "null argument");
+  if (!n) return MODES_OK;
+  if (n > 0xFFFFFFFFull) return fail (MODES_E_ARG, "too many messages");
+  modes_message *d_in = nullptr;
+  modes_fields *d_out = nullptr;
+  hipError_t e1 = hipMalloc (reinterpret_cast<void **> (&d_in), n * sizeof (modes_message));
+  hipError_t e2 = e1 == hipSuccess ? hipMalloc (reinterpret_cast<void **> (&d_out), n * sizeof (modes_fields)) : e1;
+  int rc = MODES_OK;
+  if (e2 != hipSuccess) rc = fail (MODES_E_NOMEM, "hipMalloc: %s", hipGetErrorString (e2));
+  else {
+    hipError_t e = hipMemcpy (d_in, msgs, n * sizeof (modes_message), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launch_fields (d_in, uint32_t (n), d_out, nullptr);
+    if (e == hipSuccess) e = hipMemcpy (out, d_out, n * sizeof (modes_fields), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail (MODES_E_HIP, "modes_decode_fields_host: %s", hipGetErrorString (e));
+  }
+  if (d_in) (void) hipFree (d_in);
+  if (d_out) (void) hipFree (d_out);
+  return rc;
 }
 
 int modes_engine_get_stats (const modes_engine *e, modes_stats *out)

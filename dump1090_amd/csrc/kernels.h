@@ -3,6 +3,8 @@
 #include <hip/hip_runtime_api.h>
 #include "common.h"
 
+struct modes_fields;
+
 namespace modes {
 hipError_t upload_constants (const uint32_t *single_bit, const float *uc8_float);
 hipError_t launch_scan2400 (const ScanParams &p, hipStream_t stream);
@@ -37,6 +39,8 @@ hipError_t launch_convert_float (int conv, const uint8_t *iq, uint16_t *mag, siz
                                  float *zI, float *zQ, float *mag_sq, float *z_final, float *power_out, hipStream_t stream);
 hipError_t launch_raw_format (const void *msgs, uint32_t n, uint32_t *len, uint64_t *chunk_sum, uint64_t *chunk_vp,
                               uint64_t *chunk_ovf, uint64_t *totals, uint64_t *offsets, int upper, char *text, int pass, hipStream_t stream);
+// kernels_fields.hip
+hipError_t launch_fields (const void *msgs, uint32_t n, struct ::modes_fields *out, hipStream_t stream);
 // kernels_dc.hip
 hipError_t launch_dc_chain (int conv, const DcParams &p, uint32_t ndesc, hipStream_t stream);
 hipError_t launch_dc_linear (int conv, const uint8_t *iq, uint64_t n, double A, double B, double *out, hipStream_t stream);

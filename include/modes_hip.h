@@ -273,6 +273,31 @@ typedef struct modes_d8_state {
 int  modes_engine_set_d8_state (modes_engine *e, const modes_d8_state *in);      /* applies to the next run only */
 int  modes_engine_get_d8_state (modes_engine *e, modes_d8_state *out, int want_acc, void *stream);
 
+/* Field decode of the last run's messages, batched on the device: what decode_mode_S_message() does behind its CRC /
+ * accept switch (ref: src/dump1090.c:2580-2675 with decode_extended_squitter :1901-2249 and the AC / ID / movement /
+ * callsign helpers :1494-1623,1844-1899,2771-2812) and decode_mode_A_message() (:2722-2766) for Mode A/C replies.
+ * One record per message, in message order; members carry the names and meanings of modeS_message
+ * (ref: src/misc.h:721-806).  Members the reference never writes on this path (aircraft_type, odd_flag, UTC_flag,
+ * vert_rate_source/_sign, DR_status, UM_status, BDS, MB, MV, position, source) are not part of the record. */
+typedef struct modes_fields {
+  uint32_t AC_flags;        /* MODES_ACFLAGS_* (ref: src/aircraft.h:43-64)                       */
+  uint32_t addr;            /* mm.addr, MODES_NON_ICAO_ADDRESS (bit 24) included                 */
+  uint32_t category;
+  uint16_t addrtype;        /* addrtype_t (ref: src/aircraft.h:86-97)                            */
+  uint8_t  reliable, unit;  /* unit: 0 unset, MODES_UNIT_FEET = 1, MODES_UNIT_METERS = 2         */
+  int8_t   capa; uint8_t IID; int8_t ME_type, ME_subtype, cf, reserved0; uint8_t nuc_p, EW_dir, NS_dir, reserved1[3];
+  int32_t  flight_status;
+  int32_t  identity, altitude, altitude_HAE, HAE_delta, raw_latitude, raw_longitude, EW_velocity, NS_velocity, vert_rate;
+  double   heading, velocity;
+  char     flight[9];       /* NUL-terminated */
+  uint8_t  ME[7], MD[10], reserved2[6];
+} modes_fields;             /* 120 bytes */
+/* *out points into host memory owned by the engine (valid until the next call on it). */
+int  modes_engine_decode_fields (modes_engine *e, const modes_fields **out, size_t *n, void *stream);
+/* The same on a caller's list in host memory (messages that did not come from a run: RAW / SBS input, replays); only
+ * msg, msg_type, crc and error_bits of every modes_message are read.  Runs on the current device. */
+int  modes_decode_fields_host (const modes_message *msgs, size_t n, modes_fields *out);
+
 size_t               modes_engine_num_messages (const modes_engine *e);
 const modes_message *modes_engine_messages (const modes_engine *e);      /* host memory */
 int                  modes_engine_get_stats (const modes_engine *e, modes_stats *out);

@@ -251,10 +251,256 @@ void orc_icao_import (orc_ctx *c, const uint32_t *slots) { memcpy (c->icao, slot
 static uint16_t g_last_tail[4096]; static uint32_t g_last_tail_n;
 uint32_t orc_last_tail (uint16_t *out) { memcpy (out, g_last_tail, g_last_tail_n * sizeof (uint16_t)); return g_last_tail_n; }
 
+
+/* ---------------------------------------------------------------------------------------------
+ * Field decode of an accepted message: the part of _decode_mode_S_message behind the CRC / accept
+ * switch (ref: src/dump1090.c:2580-2675) with its helpers decode_ID13_field (:1494-1514), decode_AC13_field
+ * (:1524-1559), decode_AC12_field (:1565-1592), decode_movement_field (:1597-1623), mode_A_to_mode_C (:2771-2812),
+ * set_callsign (:1844-1877), decode_BDS20 / decode_comm_B (:1882-1899), decode_extended_squitter (:1901-2249), and
+ * decode_mode_A_message (:2722-2766) for msg_type 32.  `reliable` follows :2459-2475, 2489-2540.
+ * Members of modeS_message the reference never writes on this path (aircraft_type, odd_flag, UTC_flag,
+ * vert_rate_source/_sign, DR_status, UM_status, BDS, MB, MV, position) stay zero there and are not part of orc_fields.
+ * ------------------------------------------------------------------------------------------- */
+static int f_decode_id13 (int f)
+{
+  int g = 0;
+  if (f & 0x1000) g |= 0x0010;
+  if (f & 0x0800) g |= 0x1000;
+  if (f & 0x0400) g |= 0x0020;
+  if (f & 0x0200) g |= 0x2000;
+  if (f & 0x0100) g |= 0x0040;
+  if (f & 0x0080) g |= 0x4000;
+  if (f & 0x0020) g |= 0x0100;
+  if (f & 0x0010) g |= 0x0001;
+  if (f & 0x0008) g |= 0x0200;
+  if (f & 0x0004) g |= 0x0002;
+  if (f & 0x0002) g |= 0x0400;
+  if (f & 0x0001) g |= 0x0004;
+  return g;
+}
+
+static int f_mode_a_to_c (unsigned a)
+{
+  unsigned five = 0, one = 0;
+  if ((a & 0xFFFF8889) || (a & 0xF0) == 0) return -9999;
+  if (a & 0x0010) one ^= 7;
+  if (a & 0x0020) one ^= 3;
+  if (a & 0x0040) one ^= 1;
+  if ((one & 5) == 5) one ^= 2;
+  if (one > 5) return -9999;
+  if (a & 0x0002) five ^= 0x0FF;
+  if (a & 0x0004) five ^= 0x07F;
+  if (a & 0x1000) five ^= 0x03F;
+  if (a & 0x2000) five ^= 0x01F;
+  if (a & 0x4000) five ^= 0x00F;
+  if (a & 0x0100) five ^= 0x007;
+  if (a & 0x0200) five ^= 0x003;
+  if (a & 0x0400) five ^= 0x001;
+  if (five & 1) one = 6 - one;
+  return (int)(five * 5) + (int) one - 13;
+}
+
+static int f_ac13 (int f, uint8_t *unit)
+{
+  int n;
+  if (!(f & 0x40)) {
+    *unit = 1;
+    if (f & 0x10) { n = ((f & 0x1F80) >> 2) | ((f & 0x20) >> 1) | (f & 0x0F); return n * 25 - 1000; }
+    n = f_mode_a_to_c ((unsigned) f_decode_id13 (f));
+    return n < -12 ? -9999 : 100 * n;
+  }
+  *unit = 2;
+  return -9999;
+}
+
+static int f_ac12 (int f, uint8_t *unit)
+{
+  int n;
+  *unit = 1;
+  if (f & 0x10) { n = ((f & 0x0FE0) >> 1) | (f & 0x0F); return n * 25 - 1000; }
+  n = ((f & 0x0FC0) << 1) | (f & 0x3F);
+  n = f_mode_a_to_c ((unsigned) f_decode_id13 (n));
+  return n < -12 ? -9999 : 100 * n;
+}
+
+static int f_movement (int m)
+{
+  if (m > 123) return 199;
+  if (m > 108) return (m - 108) * 5 + 100;
+  if (m > 93) return (m - 93) * 2 + 70;
+  if (m > 38) return (m - 38) + 15;
+  if (m > 12) return ((m - 11) >> 1) + 2;
+  if (m > 8) return ((m - 6) >> 2) + 1;
+  return 0;
+}
+
+static void f_callsign (orc_fields *o, uint32_t c1, uint32_t c2)
+{
+  static const char *set = "@ABCDEFGHIJKLMNOPQRSTUVWXYZ[\\]^_ !\"#$%&'()*+,-./0123456789:;<=>?";
+  static const char *junk = "[\\]^_!\"#$%&'()*+,-./:;<=>?";
+  char fl[9], *s;
+  size_t n;
+  if (c1 == 0 && c2 == 0) return;
+  fl[3] = set[c1 & 63]; c1 >>= 6; fl[2] = set[c1 & 63]; c1 >>= 6; fl[1] = set[c1 & 63]; c1 >>= 6; fl[0] = set[c1 & 63];
+  fl[7] = set[c2 & 63]; c2 >>= 6; fl[6] = set[c2 & 63]; c2 >>= 6; fl[5] = set[c2 & 63]; c2 >>= 6; fl[4] = set[c2 & 63];
+  fl[8] = 0;
+  if (strpbrk (fl, junk)) return;
+  o->AC_flags |= 0x20;
+  s = fl;                                          /* str_trim (ref: src/misc.c:661-699) */
+  while (s[0] && s[1] && s[0] == ' ') s++;
+  n = strlen (s);
+  if (n) { n--; while (n && s[n] == ' ') s[n--] = 0; }
+  strcpy (o->flight, s);
+}
+
+void orc_decode_fields (const uint8_t *msg, int msg_type, uint32_t crc, int error_bits, orc_fields *o)
+{
+  int me_type, me_sub, check_imf = 0, df = msg_type;
+  memset (o, 0, sizeof *o);
+  if (msg_type == 32) {                            /* ref: :2722-2766 */
+    const int a = (msg[0] << 8) | msg[1];
+    o->addrtype = 8;
+    o->addr = (uint32_t)(a & 0xFF7F) | 0x1000000u;
+    o->identity = a & 0x7777;
+    o->AC_flags |= 0x400;
+    o->flight_status = (int8_t)(a & 0x80);         /* an int in the reference: 0 or 128 */
+    o->flight_status_raw = a & 0x80;
+    return;
+  }
+  /* address and `reliable` as the accept switch leaves them (ref: :2406-2570) */
+  if (df == 11) { o->IID = (uint8_t)(crc & 0x7F); o->addr = ((uint32_t) msg[1] << 16) | ((uint32_t) msg[2] << 8) | msg[3]; }
+  else if (df == 17 || df == 18) { o->addr = ((uint32_t) msg[1] << 16) | ((uint32_t) msg[2] << 8) | msg[3]; o->reliable = crc == 0; }
+  else o->addr = crc;
+  (void) error_bits;
+  if (df == 0 || df == 4 || df == 16 || df == 20) {
+    const int f = ((msg[2] << 8) | msg[3]) & 0x1FFF;
+    if (f) { o->altitude = f_ac13 (f, &o->unit); if (o->altitude != -9999) o->AC_flags |= 1; }
+  }
+  if (df == 11 || df == 17) {
+    o->capa = msg[0] & 7;
+    if (o->capa == 4) o->AC_flags |= 4 | 2; else if (o->capa == 5) o->AC_flags |= 4;
+  }
+  if (df == 18) o->cf = msg[0] & 7;
+  if (df == 4 || df == 5 || df == 20 || df == 21) {
+    o->AC_flags |= 0x80000;
+    o->flight_status = msg[0] & 7; o->flight_status_raw = msg[0] & 7;
+    if (o->flight_status <= 3) { o->AC_flags |= 4; if (o->flight_status & 1) o->AC_flags |= 2; }
+  }
+  if (df == 5 || df == 21) {
+    const int f = ((msg[2] << 8) | msg[3]) & 0x1FFF;
+    if (f) { o->AC_flags |= 0x400; o->identity = f_decode_id13 (f); }
+  }
+  if ((df == 20 || df == 21) && msg[4] == 0x20)
+    f_callsign (o, ((uint32_t) msg[5] << 16) | ((uint32_t) msg[6] << 8) | msg[7], ((uint32_t) msg[8] << 16) | ((uint32_t) msg[9] << 8) | msg[10]);
+  if (df == 24) memcpy (o->MD, msg + 1, 10);
+  if (df == 17 || df == 18) {
+    memcpy (o->ME, msg + 4, 7);
+    me_type = o->ME_type = msg[4] >> 3;
+    me_sub = o->ME_subtype = me_type == 29 ? (msg[4] & 6) >> 1 : msg[4] & 7;
+    if (df == 18) {
+      switch (o->cf) {
+        case 0: o->addrtype = 1; break;
+        case 1: o->addr |= 0x1000000u; o->addrtype = 4; break;
+        case 2: o->AC_flags |= 0x4000; o->addrtype = 3; check_imf = 1; break;
+        case 3: o->AC_flags |= 0x4000; o->addrtype = 3; if (msg[4] & 0x80) o->addr |= 0x1000000u; goto vs;
+        case 5: o->AC_flags |= 0x4000; o->addr |= 0x1000000u; o->addrtype = 7; break;
+        case 6: o->addrtype = 2; check_imf = 1; break;
+        default: o->addr |= 0x1000000u; o->addrtype = 9; goto vs;
+      }
+    }
+    switch (me_type) {
+      case 1: case 2: case 3: case 4:
+        f_callsign (o, ((uint32_t) msg[5] << 16) | ((uint32_t) msg[6] << 8) | msg[7], ((uint32_t) msg[8] << 16) | ((uint32_t) msg[9] << 8) | msg[10]);
+        o->category = (uint32_t)(((0x0E - me_type) << 4) | me_sub);
+        o->AC_flags |= 0x1000;
+        break;
+      case 19: {
+        if (check_imf && (msg[5] & 0x80)) o->addr |= 0x1000000u;
+        o->AC_flags |= 4;
+        if (me_sub >= 1 && me_sub <= 4) {
+          int vr = ((msg[8] & 7) << 6) | (msg[9] >> 2);
+          if (vr) { vr--; if (msg[8] & 8) vr = -vr; o->vert_rate = vr * 64; o->AC_flags |= 0x8000; }
+        }
+        if (me_sub == 1 || me_sub == 2) {
+          const int ew_raw = ((msg[5] & 3) << 8) | msg[6], ns_raw = ((msg[7] & 0x7F) << 3) | (msg[8] >> 5);
+          int ew = ew_raw - 1, ns = ns_raw - 1;
+          if (me_sub == 2) { ns <<= 2; ew <<= 2; }
+          if (ew_raw) { o->AC_flags |= 0x100000; if (msg[5] & 4) ew = -ew; o->EW_velocity = ew; o->EW_dir = (msg[5] & 4) >> 2; }
+          if (ns_raw) { o->AC_flags |= 0x200000; if (msg[7] & 0x80) ns = -ns; o->NS_velocity = ns; o->NS_dir = (msg[7] & 0x80) >> 7; }
+          if (ew_raw && ns_raw) {
+            o->AC_flags |= 0x800 | 0x200 | 0x40000;
+            o->velocity = sqrt ((ns * ns) + (ew * ew) + 0.5);
+            if (o->velocity > 0.0001) {
+              o->heading = atan2 (ew, ns) * 180.0 / M_PI;
+              if (o->heading < 0.0) o->heading += 360.0;
+            }
+          }
+        } else if (me_sub == 3 || me_sub == 4) {
+          int as = ((msg[7] & 0x7F) << 3) | (msg[8] >> 5);
+          if (as) { o->AC_flags |= 0x800; as--; if (me_sub == 4) as <<= 2; o->velocity = as; }
+          if (msg[5] & 4) { o->AC_flags |= 0x200; o->heading = ((((msg[5] & 3) << 8) | msg[6]) * 45) >> 7; }
+        }
+        if (msg[10] != 0) { o->AC_flags |= 0x100; o->HAE_delta = ((msg[10] & 0x80) ? -25 : 25) * ((msg[10] & 0x7F) - 1); }
+        break;
+      }
+      case 5: case 6: case 7: case 8: {
+        int mv;
+        if (check_imf && (msg[6] & 8)) o->addr |= 0x1000000u;
+        o->AC_flags |= 4 | 2;
+        o->raw_latitude = ((msg[6] & 3) << 15) | (msg[7] << 7) | (msg[8] >> 1);
+        o->raw_longitude = ((msg[8] & 1) << 16) | (msg[9] << 8) | msg[10];
+        o->AC_flags |= (msg[6] & 4) ? 0x10 : 0x08;
+        mv = ((msg[4] << 4) | (msg[5] >> 4)) & 0x7F;
+        if (mv && mv < 125) { o->AC_flags |= 0x800; o->velocity = f_movement (mv); }
+        if (msg[5] & 8) { o->AC_flags |= 0x200; o->heading = ((((msg[5] << 4) | (msg[6] >> 4)) & 0x7F) * 45) >> 4; }
+        o->nuc_p = (uint8_t)(14 - me_type);
+        break;
+      }
+      case 0: case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16: case 17: case 18: case 20: case 21: case 22: {
+        const int ac12 = ((msg[5] << 4) | (msg[6] >> 4)) & 0x0FFF;
+        if (check_imf && (msg[4] & 1)) o->addr |= 0x1000000u;
+        o->AC_flags |= 4;
+        if (me_type != 0) {
+          o->raw_latitude = ((msg[6] & 3) << 15) | (msg[7] << 7) | (msg[8] >> 1);
+          o->raw_longitude = ((msg[8] & 1) << 16) | (msg[9] << 8) | msg[10];
+          if (!(ac12 == 0 && o->raw_longitude == 0 && (o->raw_latitude & 0x0FFF) == 0 && me_type == 15))
+            o->AC_flags |= (msg[6] & 4) ? 0x10 : 0x08;
+        }
+        if (ac12) {
+          if (me_type == 20 || me_type == 21 || me_type == 22) { o->altitude_HAE = f_ac12 (ac12, &o->unit); if (o->altitude_HAE != -9999) o->AC_flags |= 0x80; }
+          else { o->altitude = f_ac12 (ac12, &o->unit); if (o->altitude != -9999) o->AC_flags |= 1; }
+        }
+        if (me_type == 0 || me_type == 18 || me_type == 22) o->nuc_p = 0;
+        else if (me_type < 18) o->nuc_p = (uint8_t)(18 - me_type);
+        else o->nuc_p = (uint8_t)(29 - me_type);
+        break;
+      }
+      case 23:
+        if (me_sub == 7) { const int f = (((msg[5] << 8) | msg[6]) & 0xFFF1) >> 3; if (f) { o->AC_flags |= 0x400; o->identity = f_decode_id13 (f); } }
+        break;
+      case 24: break;
+      case 28:
+        if (me_sub == 1) {
+          const int f = ((msg[5] << 8) | msg[6]) & 0x1FFF;
+          if (f) { o->AC_flags |= 0x400; o->identity = f_decode_id13 (f); }
+          if (check_imf && (msg[10] & 1)) o->addr |= 0x1000000u;
+        }
+        break;
+      case 29: case 30: break;
+      case 31: if (check_imf && (msg[10] & 1)) o->addr |= 0x1000000u; break;
+      default: o->reliable = 0; break;
+    }
+  }
+vs:
+  if (df == 0 || df == 16) { o->AC_flags |= 4; if (msg[0] & 4) o->AC_flags |= 2; }
+}
+
 /* ref: src/dump1090.c:3423-3448 (strip_mode_loop): uc8 IQ pairs whose I and Q are both within `level` of 127 are
  * dropped once more than 4 * MODES_PREAMBLE_US = 32 of them follow each other; everything else is copied.
  * *run_io: the counter `c` of the reference (quiet samples in a row so far), carried from call to call.
  * A trailing odd byte is not a pair and is ignored (the loop ends at the first EOF). */
+size_t orc_sizeof_fields (void) { return sizeof (orc_fields); }
+
 size_t orc_strip (const uint8_t *in, size_t nbytes, int level, uint64_t *run_io, uint8_t *out)
 {
   uint64_t c = run_io ? *run_io : 0;

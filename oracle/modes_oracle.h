@@ -142,6 +142,24 @@ void     orc_icao_export (const orc_ctx *c, uint32_t *slots1024);
 void     orc_icao_import (orc_ctx *c, const uint32_t *slots1024);
 uint32_t orc_last_tail (uint16_t *out);
 
+/* ---- field decode of an accepted message (ref: src/dump1090.c:2580-2675 and helpers; see modes_oracle.c) ----
+ * msg: the message bytes after CRC repair; msg_type as in orc_msg (24 for DF24..31, 32 for Mode A/C); crc = mm.CRC. */
+typedef struct orc_fields {
+  uint32_t AC_flags;        /* MODES_ACFLAGS_* (ref: src/aircraft.h:43-64) */
+  uint32_t addr;            /* mm.addr, MODES_NON_ICAO_ADDRESS included */
+  uint32_t category;
+  uint16_t addrtype;        /* addrtype_t (ref: src/aircraft.h:86-97) */
+  uint8_t  reliable, unit;  /* unit: 0 unset, 1 feet, 2 meters */
+  int8_t   capa; uint8_t IID; int8_t ME_type, ME_subtype, cf, flight_status; uint8_t nuc_p, EW_dir, NS_dir, pad0[3];
+  int32_t  flight_status_raw;   /* mm.flight_status as the int it is (Mode A/C stores 0 / 128 there) */
+  int32_t  identity, altitude, altitude_HAE, HAE_delta, raw_latitude, raw_longitude, EW_velocity, NS_velocity, vert_rate;
+  double   heading, velocity;
+  char     flight[9];
+  uint8_t  ME[7], MD[10], pad1[6];
+} orc_fields;
+void orc_decode_fields (const uint8_t *msg, int msg_type, uint32_t crc, int error_bits, orc_fields *out);
+size_t orc_sizeof_fields (void);
+
 /* ---- --strip (ref: src/dump1090.c:3423-3448): returns the bytes written to `out` (room for nbytes) ---- */
 size_t   orc_strip (const uint8_t *in, size_t nbytes, int level, uint64_t *run_io, uint8_t *out);
 

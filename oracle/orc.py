@@ -246,6 +246,28 @@ def convert(conv_id, iq, nsamples, sample_rate=2400000.0, filter_dc=False, state
     return mag, p.value, state
 
 
+FIELDS_DTYPE = np.dtype([("AC_flags", "<u4"), ("addr", "<u4"), ("category", "<u4"), ("addrtype", "<u2"), ("reliable", "u1"),
+                         ("unit", "u1"), ("capa", "i1"), ("IID", "u1"), ("ME_type", "i1"), ("ME_subtype", "i1"), ("cf", "i1"),
+                         ("flight_status8", "i1"), ("nuc_p", "u1"), ("EW_dir", "u1"), ("NS_dir", "u1"), ("pad0", "u1", (3,)),
+                         ("flight_status", "<i4"), ("identity", "<i4"), ("altitude", "<i4"), ("altitude_HAE", "<i4"),
+                         ("HAE_delta", "<i4"), ("raw_latitude", "<i4"), ("raw_longitude", "<i4"), ("EW_velocity", "<i4"),
+                         ("NS_velocity", "<i4"), ("vert_rate", "<i4"), ("pad", "<u4"), ("heading", "<f8"), ("velocity", "<f8"),
+                         ("flight", "S9"), ("ME", "u1", (7,)), ("MD", "u1", (10,)), ("pad1", "u1", (6,))])
+
+
+def decode_fields(msgs):
+    """orc_decode_fields over an array with fields msg, msg_type, crc, error_bits (engine or oracle message dtype)."""
+    L = lib()
+    L.orc_sizeof_fields.restype = C.c_size_t
+    assert L.orc_sizeof_fields() == FIELDS_DTYPE.itemsize
+    L.orc_decode_fields.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p]
+    out = np.zeros(len(msgs), dtype=FIELDS_DTYPE)
+    for i, m in enumerate(msgs):
+        b = np.ascontiguousarray(m["msg"], dtype=np.uint8)
+        L.orc_decode_fields(_ptr(b), int(m["msg_type"]), int(m["crc"]), int(m["error_bits"]), C.c_void_p(out.ctypes.data + i * out.itemsize))
+    return out
+
+
 def strip(iq, level, run=0):
     """strip_mode_loop (ref: src/dump1090.c:3423-3448) over a uint8 buffer; returns (kept bytes, counter carried out)."""
     a = np.ascontiguousarray(iq, dtype=np.uint8)

@@ -169,3 +169,17 @@ def test_strip_fixed_point_modes1(modes1):
     assert runs.max() == 32 and (runs == 32).sum() > 1000
     out30, _ = orc.strip(modes1, 30)
     assert out30.size < modes1.size
+
+
+def test_field_decode_readme_pair():
+    """What the reference prints for the two README messages (README.md:289-305) pins the field decode's CA, FS and
+    AC (25 ft, Q bit) paths: DF11 capability 5 "is airborne", ICAO 4d2023; DF4 "Normal, Airborne", 23375 feet."""
+    msgs = np.zeros(2, dtype=orc.MSG_DTYPE)
+    for i, (hx, df, crc) in enumerate((("5d4d20237a55a6", 11, 0), ("20000f1f684a6c", 4, 0x4D2023))):
+        b = bytes.fromhex(hx)
+        msgs[i]["msg"][: len(b)] = np.frombuffer(b, dtype=np.uint8)
+        msgs[i]["msg_type"], msgs[i]["crc"], msgs[i]["msg_bits"] = df, crc, 56
+    f = orc.decode_fields(msgs)
+    assert f[0]["capa"] == 5 and f[0]["addr"] == 0x4D2023 and f[0]["AC_flags"] & 0x4 and not f[0]["AC_flags"] & 0x2
+    assert f[1]["flight_status"] == 0 and f[1]["altitude"] == 23375 and f[1]["unit"] == 1 and f[1]["addr"] == 0x4D2023
+    assert f[1]["AC_flags"] & 0x1 and f[1]["AC_flags"] & 0x80000
