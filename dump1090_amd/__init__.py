@@ -146,6 +146,15 @@ def lib():
         L.modes_engine_get_d8_state.argtypes = [C.c_void_p, C.POINTER(D8State), C.c_int, C.c_void_p]
         L.modes_engine_decode_fields.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p]
         L.modes_decode_fields_host.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.modes_live_open.argtypes = [C.POINTER(EngineConfig), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.modes_live_close.argtypes = [C.c_void_p]
+        L.modes_live_close.restype = None
+        L.modes_live_rx.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.modes_live_take.restype = C.c_size_t
+        L.modes_live_take.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        L.modes_live_flush.argtypes = [C.c_void_p]
+        L.modes_live_hold.argtypes = [C.c_void_p, C.c_int]
+        L.modes_live_get_stats.argtypes = [C.c_void_p, C.POINTER(LiveStats)]
         L.modes_engine_num_messages.restype = C.c_size_t
         L.modes_engine_num_messages.argtypes = [C.c_void_p]
         L.modes_engine_messages.restype = C.c_void_p
@@ -341,6 +350,58 @@ class Engine:
         s = Stats()
         _check(self.L.modes_engine_get_stats(self.h, C.byref(s)))
         return s.asdict()
+
+
+class LiveStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("blocks", "samples", "dropped_blocks", "dropped_samples", "discontinuities",
+                                          "blocks_decoded", "messages")]
+
+    def asdict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class Live:
+    """modes_live_*: rx_callback() + FIFO + main_data_loop() around the device path (include/modes_hip.h)."""
+
+    def __init__(self, sample_rate=2400000, input_format=INPUT_UC8, max_block_bytes=0, nbuffers=4, **kw):
+        self.L = lib()
+        cfg = EngineConfig(sample_rate=sample_rate, input_format=input_format, filter_dc=int(kw.get("filter_dc", False)),
+                           compute_power=int(kw.get("compute_power", False)), fix_bits=kw.get("fix_bits", 1),
+                           phase_enhance=int(kw.get("phase_enhance", False)), mode_ac=int(kw.get("mode_ac", False)),
+                           device=kw.get("device", 0), host_replay=0)
+        h = C.c_void_p()
+        _check(self.L.modes_live_open(C.byref(cfg), max_block_bytes, nbuffers, C.byref(h)))
+        self.h = h
+
+    def rx(self, block):
+        b = np.ascontiguousarray(block)
+        rc = self.L.modes_live_rx(self.h, b.ctypes.data_as(C.c_void_p), b.nbytes)
+        if rc < 0:
+            _check(rc)
+        return rc
+
+    def take(self, max_n=1 << 16, wait_ms=0):
+        buf = np.zeros(max_n, dtype=MESSAGE_DTYPE)
+        n = self.L.modes_live_take(self.h, buf.ctypes.data_as(C.c_void_p), max_n, wait_ms)
+        return buf[:n].copy()
+
+    def flush(self):
+        _check(self.L.modes_live_flush(self.h))
+
+    def hold(self, on):
+        _check(self.L.modes_live_hold(self.h, int(on)))
+
+    def stats(self):
+        s = LiveStats()
+        _check(self.L.modes_live_get_stats(self.h, C.byref(s)))
+        return s.asdict()
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.modes_live_close(self.h)
+            self.h = None
+
+    __del__ = close
 
 
 def convert_device(conv_id, d_iq_ptr, d_mag_ptr, nsamples, state=None, want_power=True, stream=None):

@@ -743,7 +743,9 @@ static int run_device_inner (modes_engine *e, const void *d_iq, size_t nbytes, u
 {
   if (!e || (!d_iq && nbytes)) return fail (MODES_E_ARG, "null argument");
   hipStream_t stream = static_cast<hipStream_t> (stream_v);
-  if (first_sample % e->block_samples) return fail (MODES_E_ARG, "first_sample must be a multiple of the block length");
+  // a run of several blocks starts on a block boundary; a single block (a live receiver's buffer) may start anywhere
+  if (first_sample % e->block_samples && nbytes / bytes_per_sample (e->cfg.input_format) > e->block_samples)
+    return fail (MODES_E_ARG, "first_sample must be a multiple of the block length");
   HIP_TRY (hipSetDevice (e->cfg.device));
   e->messages.clear ();
   e->in_pinned = false; e->pin_n = 0;
@@ -960,7 +962,8 @@ static int run_mode_ac_2400 (modes_engine *e, const void *d_iq, size_t nbytes, u
 static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t first_sample, const uint16_t *d_halo,
                      hipStream_t stream)
 {
-  if (first_sample % e->block_samples) return fail (MODES_E_ARG, "first_sample must be a multiple of the block length");
+  if (first_sample % e->block_samples && nbytes / bytes_per_sample (e->cfg.input_format) > e->block_samples)
+    return fail (MODES_E_ARG, "first_sample must be a multiple of the block length");
   HIP_TRY (hipSetDevice (e->cfg.device));
   e->messages.clear ();
   e->in_pinned = false; e->pin_n = 0;

@@ -342,6 +342,31 @@ int  modes_engine_read_dc_magnitudes (modes_engine *e, uint16_t *out, size_t fir
  * cannot wait for the previous shard's tail.  at_sample must be a multiple of the block length. */
 int  modes_engine_halo_at (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t at_sample, uint16_t *d_out, void *stream);
 
+/* ---- live receivers: rx_callback() + mag_buf FIFO + main_data_loop() around the device path ----
+ * (ref: src/dump1090.c:1181-1282,1367-1400, src/fifo.c:195-211).  A reader thread hands over IQ blocks with
+ * modes_live_rx(); a worker owned by the object converts and demodulates them on the device in arrival order, carrying
+ * the overlap from block to block; modes_live_take() drains the decoded messages.  Blocks are converted before they are
+ * queued for the demodulator (the reference enqueues first, src/dump1090.c:1273-1282) and staged in pinned host buffers.
+ * Block timestamps come from a sample counter that only counts accepted blocks; when every buffer is busy the block is
+ * dropped and the next accepted block is discontinuous: its overlap is zeros (ref: src/dump1090.c:1187-1207,
+ * src/fifo.c:197-203).  In the messages `block` counts the accepted blocks and `reserved` carries
+ * mm.sys_timestamp_msg in ms since modes_live_open(). */
+typedef struct modes_live modes_live;
+typedef struct modes_live_stats {
+  uint64_t blocks, samples;              /* accepted                                   */
+  uint64_t dropped_blocks, dropped_samples, discontinuities;
+  uint64_t blocks_decoded, messages;
+} modes_live_stats;
+/* max_block_bytes: the largest block modes_live_rx() will see (0 = 256 KiB, MODES_ASYNC_BUF_SIZE, also the maximum);
+ * nbuffers: pinned buffers in the ring (2..64). */
+int    modes_live_open (const modes_engine_config *cfg, uint32_t max_block_bytes, uint32_t nbuffers, modes_live **out);
+void   modes_live_close (modes_live *l);
+int    modes_live_rx (modes_live *l, const void *iq, uint32_t len);    /* 1 = queued, 0 = dropped, < 0 = error; never waits for the device */
+size_t modes_live_take (modes_live *l, modes_message *out, size_t max, int wait_ms);
+int    modes_live_flush (modes_live *l);                               /* until every queued block is decoded */
+int    modes_live_hold (modes_live *l, int hold);                      /* 1: the worker leaves the queue alone (a stalled consumer); 0: resume */
+int    modes_live_get_stats (modes_live *l, modes_live_stats *out);
+
 /* --strip as a streaming pass (ref: src/dump1090.c:3423-3448, strip_mode_loop; README "What is --strip mode?"):
  * uc8 IQ pairs whose I and Q both lie within `level` of 127 are dropped from the 33rd pair of such a run on, all other
  * pairs are copied in order.  d_iq (16-byte aligned) and d_out (room for nbytes) are device memory; *out_bytes receives
