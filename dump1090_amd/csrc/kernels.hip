@@ -20,16 +20,20 @@ namespace modes {
 
 
 
-// LDS per wave
+// A wave scans PAIR consecutive strips and feeds their candidates through ONE queue, so that the 64-lane batches of
+// stages C and D run fuller.  Measured (profiles/r02_pmc_scan_stages.json, tools/ab.sh): PAIR = 2 cuts the VALU
+// instructions per strip by 18 % (uc8 byte table) / 10 % (sc16), but its 8 KB of magnitudes per wave leave room for 4
+// waves per SIMD instead of 6, and the kernel is as sensitive to that (4 against 6 waves with single strips: +20 %
+// time) as to the instruction count: the byte-table instance comes out 3.6 % faster, the sc16 one 6 % slower.  So the
+// byte-table converters run with PAIR = 2, the others with single strips.
+template <int CONV> struct ScanPair { static constexpr int n = (CONV == kConvUc8Lut || CONV == kConvUc8LutPower) ? 2 : 1; };
 constexpr int kWavesPerBlock = 4;
-constexpr int kGroupSpan = kWavesPerBlock * kStrip;             // positions one workgroup scans
-constexpr int kTileN = 8 * TileChunks<kGroupSpan + kLook2400>::n;
 constexpr int kQ1Seg = 256;
 constexpr uint32_t kSynSkipped = 0x80000000u;      // stage D1 did not slice the candidate: the reference never looks at it
-template <bool PE> struct WaveLds {
+template <bool PE, int PAIR> struct WaveLds {
   uint16_t q1[kQ1Seg];                              // off | pattern << 12, kQ1Seg candidates at a time
   uint32_t q2[PE ? 5 * 64 : 64];                    // off | (t-4) << 12 | df << 16, one stage-C batch at a time
-  uint32_t vp[kStrip / 32];                         // valid-preamble bit per position of the strip
+  uint32_t vp[PAIR * kStrip / 32];                  // valid-preamble bit per position of the span
 };
 
 
@@ -83,111 +87,133 @@ __global__ __launch_bounds__ (64 * kWavesPerBlock) __attribute__ ((amdgpu_waves_
 void scan2400_kernel (const ScanParams p)
 {
   constexpr bool kLut = CONV == kConvUc8Lut || CONV == kConvUc8LutPower;
-  __shared__ WaveLds<PE> lds[kWavesPerBlock];
+  constexpr int kPair = PE ? 1 : ScanPair<CONV>::n;
+  constexpr int kSpan = kPair * kStrip;                           // positions one wave scans
+  constexpr int kGroupSpan = kWavesPerBlock * kSpan;              // positions one workgroup scans
+  constexpr int kStageHalf = kGroupSpan / 2;                      // the tile is staged in two goes (registers)
+  constexpr int kTileN = kStageHalf + 8 * TileChunks<kStageHalf + kLook2400>::n;
+  static_assert (kSpan <= 4096, "queue entries keep a position of the span in 12 bits");
+  __shared__ WaveLds<PE, kPair> lds[kWavesPerBlock];
   __shared__ __attribute__ ((aligned (16))) uint16_t s_tile[kTileLead + kTileN];   // s_tile[kTileLead + x] = V[G0 + x], shared by the four waves
   __shared__ uint16_t s_lut[kLut ? 256 : 1];        // as-written uc8 table
   const int lane = lane_id ();
   const int wv = threadIdx.x >> 6;
-  WaveLds<PE> &w = lds[wv];
+  WaveLds<PE, kPair> &w = lds[wv];
   if (kLut) {
     s_lut[threadIdx.x] = p.lut256[threadIdx.x];
     __syncthreads ();
   }
-  const uint32_t strip = blockIdx.x * kWavesPerBlock + wv;
-  w.vp[lane] = 0;
+  const uint32_t strip = (blockIdx.x * kWavesPerBlock + wv) * kPair;         // first strip of this wave's span
+#pragma unroll
+  for (int h = 0; h < kPair; h++) w.vp[64 * h + lane] = 0;
 
   // stage D maps lane -> message bit (lane ^ 7) (+ 64 in the second round): a ballot then holds the message bytes as they
   // lie in memory.  Single-bit syndromes of those bits for 112-bit and 56-bit CRCs (ref: src/crc.c:35,56-61)
   const int bl = lane ^ 7;
   const uint32_t sbL0 = c_single_bit[bl], sbL1 = bl < 48 ? c_single_bit[64 + bl] : 0u, sbS = bl < 56 ? c_single_bit[56 + bl] : 0u;
 
-  // ---- stage A: magnitudes V[G0 .. G0 + 4 strips + kLook2400) into LDS, staged by the whole workgroup ----
+  // ---- stage A: magnitudes V[G0 .. G0 + 4 spans + kLook2400) into LDS, staged by the whole workgroup in two goes ----
   const long long G0 = (long long) blockIdx.x * kGroupSpan;
   const long long s0 = G0 - (long long) (CONV == kConvMagU16 ? 0u : p.ov);   // sample index of V[G0] (may be < 0)
-  stage_tile_pos<CONV, kGroupSpan + kLook2400, 64 * kWavesPerBlock> (s_tile + kTileLead, s_lut, p, s0, int (threadIdx.x));
+  stage_tile_pos<CONV, kStageHalf, 64 * kWavesPerBlock> (s_tile + kTileLead, s_lut, p, s0, int (threadIdx.x));
+  stage_tile_pos<CONV, kStageHalf + kLook2400, 64 * kWavesPerBlock> (s_tile + kTileLead + kStageHalf, s_lut, p, s0 + kStageHalf, int (threadIdx.x));
   __syncthreads ();
   if (strip >= p.nstrips) return;
   const long long P0 = (long long) strip * kStrip;
-  const uint16_t *V = s_tile + kTileLead + wv * kStrip;
+  const uint16_t *V = s_tile + kTileLead + wv * kSpan;
 
   if (p.debug_stop == 1) { if (lane == 0) p.counts[strip] = V[lane]; return; }
 
-  // ---- stage B: lane l owns positions [32 l, 32 l + 32): LT/GT bit planes from its own 33 samples ----
-  uint32_t LT = 0, GT = 0;
-  {
-    const uint4 *vw = reinterpret_cast<const uint4 *> (V + 32 * lane);
-    const uint4 x0 = vw[0], x1 = vw[1], x2 = vw[2], x3 = vw[3];
-    const uint32_t wd[17] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w,
-                              uint32_t (V[32 * lane + 32]) };
+  // ---- stage B, once per strip of the span: lane l owns positions [32 l, 32 l + 32) of the strip: LT/GT bit planes ----
+  uint32_t any[kPair], c0[kPair], c1[kPair], c2[kPair];
 #pragma unroll
-    for (int k = 31; k >= 0; k--) {
-      const int a = int ((wd[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
-      const int b = int ((wd[(k + 1) >> 1] >> (16 * ((k + 1) & 1))) & 0xFFFFu);
-      const int d = a - b;
-      LT = alignbit (LT, uint32_t (d), 31);        // shifts in (a < b)
-      GT = alignbit (GT, uint32_t (-d), 31);       // shifts in (a > b)
+  for (int h = 0; h < kPair; h++) {
+    const uint16_t *Vh = V + h * kStrip;
+    uint32_t LT = 0, GT = 0;
+    {
+      const uint4 *vw = reinterpret_cast<const uint4 *> (Vh + 32 * lane);
+      const uint4 x0 = vw[0], x1 = vw[1], x2 = vw[2], x3 = vw[3];
+      const uint32_t wd[17] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w,
+                                uint32_t (Vh[32 * lane + 32]) };
+#pragma unroll
+      for (int k = 31; k >= 0; k--) {
+        const int a = int ((wd[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+        const int b = int ((wd[(k + 1) >> 1] >> (16 * ((k + 1) & 1))) & 0xFFFFu);
+        const int d = a - b;
+        LT = alignbit (LT, uint32_t (d), 31);        // shifts in (a < b)
+        GT = alignbit (GT, uint32_t (-d), 31);       // shifts in (a > b)
+      }
     }
-  }
-  uint32_t LTn = dpp_mov<0x130, 0xF, true> (LT), GTn = dpp_mov<0x130, 0xF, true> (GT);   // wave_shl:1 = lane + 1's word
-  {   // the word behind the strip, for lane 63
-    const uint32_t a = V[kStrip + (lane & 15)], b = V[kStrip + (lane & 15) + 1];
-    const uint32_t l = uint32_t (__ballot (a < b)) & 0xFFFFu, g = uint32_t (__ballot (a > b)) & 0xFFFFu;
-    if (lane == 63) { LTn = l; GTn = g; }
-  }
+    uint32_t LTn = dpp_mov<0x130, 0xF, true> (LT), GTn = dpp_mov<0x130, 0xF, true> (GT);   // wave_shl:1 = lane + 1's word
+    {   // the word behind the strip, for lane 63
+      const uint32_t a = Vh[kStrip + (lane & 15)], b = Vh[kStrip + (lane & 15) + 1];
+      const uint32_t l = uint32_t (__ballot (a < b)) & 0xFFFFu, g = uint32_t (__ballot (a > b)) & 0xFFFFu;
+      if (lane == 63) { LTn = l; GTn = g; }
+    }
 
-  // peaks P_k = (p[k] < p[k+1] > p[k+2]); the five layouts of ref: src/demod-2400.c:225-282 with the
-  // quick check (p0 < p1, p12 > p13) folded in.
+    // peaks P_k = (p[k] < p[k+1] > p[k+2]); the five layouts of ref: src/demod-2400.c:225-282 with the
+    // quick check (p0 < p1, p12 > p13) folded in.
 #define LTk(k) alignbit (LTn, LT, k)
 #define GTk(k) alignbit (GTn, GT, k)
-  const uint32_t P0m = LT & GTk (1), P2m = LTk (2) & GTk (3), P8m = LTk (8) & GTk (9), P11m = LTk (11) & GTk (12);
-  const uint32_t P3m = LTk (3) & GTk (4), P9m = LTk (9) & GTk (10);
-  const uint32_t t389 = P0m & P2m & P8m;
-  const uint32_t ph3 = t389 & LTk (10) & GTk (12);
-  const uint32_t ph4 = t389 & P11m;
-  const uint32_t ph5 = P0m & P11m & LTk (2) & GTk (4) & LTk (8) & GTk (10);
-  const uint32_t u39b = P3m & P9m & P11m;
-  const uint32_t ph6 = P0m & u39b;
-  const uint32_t ph7 = LT & GTk (2) & u39b;
+    const uint32_t P0m = LT & GTk (1), P2m = LTk (2) & GTk (3), P8m = LTk (8) & GTk (9), P11m = LTk (11) & GTk (12);
+    const uint32_t P3m = LTk (3) & GTk (4), P9m = LTk (9) & GTk (10);
+    const uint32_t t389 = P0m & P2m & P8m;
+    const uint32_t ph3 = t389 & LTk (10) & GTk (12);
+    const uint32_t ph4 = t389 & P11m;
+    const uint32_t ph5 = P0m & P11m & LTk (2) & GTk (4) & LTk (8) & GTk (10);
+    const uint32_t u39b = P3m & P9m & P11m;
+    const uint32_t ph6 = P0m & u39b;
+    const uint32_t ph7 = LT & GTk (2) & u39b;
 #undef LTk
 #undef GTk
-  uint32_t any = ph3 | ph4 | ph5 | ph6 | ph7;
-  {   // positions at or beyond the end of the stream are not scanned (ref: src/demod-2400.c:200)
-    const long long base = P0 + 32ll * lane, N = (long long) p.nsamples;
-    if (base >= N) any = 0;
-    else if (base + 32 > N) any &= (~0u) >> (32 - int (N - base));
+    uint32_t anyh = ph3 | ph4 | ph5 | ph6 | ph7;
+    {   // positions at or beyond the end of the stream are not scanned (ref: src/demod-2400.c:200)
+      const long long base = P0 + (long long) h * kStrip + 32ll * lane, N = (long long) p.nsamples;
+      if (base >= N) anyh = 0;
+      else if (base + 32 > N) anyh &= (~0u) >> (32 - int (N - base));
+    }
+    // first matching layout wins (else-if chain): code planes of the layout index 0..4
+    const uint32_t n3 = ~ph3, n34 = n3 & ~ph4, n345 = n34 & ~ph5;
+    const uint32_t e6 = ph6 & n345, e7 = anyh & n345 & ~ph6;
+    any[h] = anyh; c0[h] = (ph4 & n3) | e6; c1[h] = (ph5 & n34) | e6; c2[h] = e7;
   }
-  // first matching layout wins (else-if chain): code planes of the layout index 0..4
-  const uint32_t n3 = ~ph3, n34 = n3 & ~ph4, n345 = n34 & ~ph5;
-  const uint32_t e6 = ph6 & n345, e7 = any & n345 & ~ph6;
-  const uint32_t c0 = (ph4 & n3) | e6, c1 = (ph5 & n34) | e6, c2 = e7;
 
-  if (p.debug_stop == 2) { if (any == 0x1234567u) p.counts[strip] = 1; return; }
-  // ---- candidates in ascending order, kQ1Seg at a time through queue 1 ----
-  const int mycnt = __popc (any);
-  const int incl = wave_incl_scan (mycnt, lane);
-  const int n1 = __builtin_amdgcn_readlane (incl, 63);      // scalar: the loops below branch on the scalar unit
+  if (p.debug_stop == 2) { if ((any[0] ^ any[kPair - 1]) == 0x1234567u) p.counts[strip] = 1; return; }
+  // ---- candidates in ascending order (strip by strip, lane by lane), kQ1Seg at a time through queue 1 ----
+  int mycnt[kPair], first_slot[kPair];
+  int n1 = 0;
+#pragma unroll
+  for (int h = 0; h < kPair; h++) {
+    mycnt[h] = __popc (any[h]);
+    const int incl = wave_incl_scan (mycnt[h], lane);
+    first_slot[h] = n1 + incl - mycnt[h];
+    n1 += __builtin_amdgcn_readlane (incl, 63);             // scalar: the loops below branch on the scalar unit
+  }
   bool overflow = false;
-  uint32_t valid_preamble = 0, nrec = 0;
+  uint32_t valid_preamble[kPair], nrec[kPair];
+#pragma unroll
+  for (int h = 0; h < kPair; h++) { valid_preamble[h] = 0; nrec[h] = 0; }
   Record *out = p.records + size_t (strip) * p.cap;
-  // Skip-ahead known inside the strip (ref: src/demod-2400.c:514): behind a message that the reference certainly
+  // Skip-ahead known inside the span (ref: src/demod-2400.c:514): behind a message that the reference certainly
   // reaches and certainly accepts (DF11/17/18 with syndrome 0: score and accept rules ask the ICAO cache nothing,
   // ref: src/dump1090.c:3309-3353,2440-2578) it never looks at the next msglen*12/5 positions, so candidates there
   // are dropped before the slicer.  c_end: positions below are certainly skipped; u_end: positions below may be
-  // skipped by a message whose acceptance depends on the ICAO cache or on what earlier strips found (a block's first
-  // strip starts with nothing pending: each demod_2400 call starts at j = 0).
+  // skipped by a message whose acceptance depends on the ICAO cache or on what earlier spans found (a block's first
+  // strip starts with nothing pending: each demod_2400 call starts at j = 0; blocks are whole spans).
   int c_end = 0;
   uint32_t r_m0lo = 0, r_m0hi = 0, r_m1lo = 0, r_m1hi = 0, r_syn = 0;   // per-lane results of stage D1 (lane = candidate of the batch)
   int u_end = (p.block_strips ? strip % p.block_strips == 0 : strip == 0) ? 0 : kLongBits * 12 / 5;
 
   for (int seg = 0; seg < n1 && !overflow; seg += kQ1Seg) {
-    {
-      int slot = incl - mycnt - seg;
-      uint32_t mm = any;
+#pragma unroll
+    for (int h = 0; h < kPair; h++) {
+      int slot = first_slot[h] - seg;
+      uint32_t mm = any[h];
       while (mm) {
         const int b = __builtin_ctz (mm);
         mm &= mm - 1;
-        const uint32_t pat = ((c0 >> b) & 1u) | (((c1 >> b) & 1u) << 1) | (((c2 >> b) & 1u) << 2);
-        if (uint32_t (slot) < uint32_t (kQ1Seg)) w.q1[slot] = uint16_t ((32 * lane + b) | (pat << 12));
+        const uint32_t pat = ((c0[h] >> b) & 1u) | (((c1[h] >> b) & 1u) << 1) | (((c2[h] >> b) & 1u) << 2);
+        if (uint32_t (slot) < uint32_t (kQ1Seg)) w.q1[slot] = uint16_t ((h * kStrip + 32 * lane + b) | (pat << 12));
         slot++;
       }
     }
@@ -264,7 +290,11 @@ void scan2400_kernel (const ScanParams p)
           }
         }
       }
-      valid_preamble += __popcll (__ballot (pass));                                       // ref: :326
+      {                                                                                   // ref: :326
+        const u64 pm = __ballot (pass), hi = kPair > 1 ? __ballot (pass && off >= kStrip) : 0ull;
+        valid_preamble[0] += __popcll (pm & ~hi);
+        if (kPair > 1) valid_preamble[kPair - 1] += __popcll (hi);
+      }
       if (pass) atomicOr (&w.vp[off >> 5], 1u << (off & 31));
       const int inc = wave_incl_scan (nent, lane);
       const int n2 = __builtin_amdgcn_readlane (inc, 63);   // <= kQ2Cap by construction
@@ -341,31 +371,38 @@ void scan2400_kernel (const ScanParams p)
           }
         }
         (void) tab;
-        const u64 kept = __ballot (keep);
-        const uint32_t slot = nrec + uint32_t (__popcll (kept & ((1ull << lane) - 1)));
-        const uint32_t total = nrec + uint32_t (__popcll (kept));
-        if (total > p.cap) { overflow = true; break; }
+        // records go to the slots of the strip they lie in; the batch is in ascending order, so first strip's come first
+        const bool second = kPair > 1 && coff >= kStrip;
+        const u64 kept = __ballot (keep), kept_hi = kPair > 1 ? __ballot (keep && second) : 0ull;
+        const u64 mine = second ? kept_hi : kept & ~kept_hi;
+        const uint32_t slot = (second ? nrec[kPair - 1] : nrec[0]) + uint32_t (__popcll (mine & ((1ull << lane) - 1)));
+        const uint32_t total0 = nrec[0] + uint32_t (__popcll (kept & ~kept_hi)), total1 = nrec[kPair - 1] + uint32_t (__popcll (kept_hi));
+        if (total0 > p.cap || total1 > p.cap) { overflow = true; break; }
         if (keep && p.write_records) {
           // Record layout: off,phase,df | cls,nerr,bit0,bit1 | crc | msg[0..13] | flags,pad
           uint4 lo4, hi4;
-          lo4.x = uint32_t (coff) | (uint32_t (t) << 16) | (uint32_t (df) << 24);
+          lo4.x = uint32_t (coff & (kStrip - 1)) | (uint32_t (t) << 16) | (uint32_t (df) << 24);
           lo4.y = uint32_t (cls) | (uint32_t (uint8_t (nerr)) << 8) | (uint32_t (uint8_t (b0)) << 16) | (uint32_t (uint8_t (b1)) << 24);
           lo4.z = syn;
           lo4.w = r_m0lo;
           hi4.x = r_m0hi; hi4.y = r_m1lo; hi4.z = r_m1hi & 0xFFFFu; hi4.w = 0;
-          uint4 *dst = reinterpret_cast<uint4 *> (out + slot);
+          uint4 *dst = reinterpret_cast<uint4 *> (out + (second ? p.cap : 0u) + slot);
           dst[0] = lo4; dst[1] = hi4;
         }
-        nrec = total;
+        nrec[0] = total0; if (kPair > 1) nrec[kPair - 1] = total1;
       }
     }
   }
-  if (p.debug_stop == 3) { if (lane == 0) p.counts[strip] = valid_preamble; return; }
+  if (p.debug_stop == 3) { if (lane == 0) p.counts[strip] = valid_preamble[0] + valid_preamble[kPair - 1]; return; }
 
-  if (p.vp_bitmap) reinterpret_cast<uint32_t *> (p.vp_bitmap)[size_t (strip) * (kStrip / 32) + lane] = w.vp[lane];
-  if (lane == 0) {      // per-strip results only: no contended atomics
-    p.counts[strip] = overflow ? 0xFFFFFFFFu : nrec;
-    p.vp_counts[strip] = valid_preamble;
+#pragma unroll
+  for (int h = 0; h < kPair; h++) {
+    if (strip + h >= p.nstrips) break;
+    if (p.vp_bitmap) reinterpret_cast<uint32_t *> (p.vp_bitmap)[size_t (strip + h) * (kStrip / 32) + lane] = w.vp[64 * h + lane];
+    if (lane == 0) {      // per-strip results only: no contended atomics
+      p.counts[strip + h] = overflow ? 0xFFFFFFFFu : nrec[h];
+      p.vp_counts[strip + h] = valid_preamble[h];
+    }
   }
 }
 
@@ -1220,10 +1257,14 @@ hipError_t upload_constants (const uint32_t *single_bit, const float *uc8_float)
 
 hipError_t launch_scan2400 (const ScanParams &p, hipStream_t stream)
 {
-  const dim3 grid ((p.nstrips + kWavesPerBlock - 1) / kWavesPerBlock), block (64 * kWavesPerBlock);
+  const dim3 block (64 * kWavesPerBlock);
   if (p.nstrips == 0) return hipSuccess;
+  if (p.block_strips % 2) return hipErrorInvalidValue;            // a block is whole spans (block_strips 0: a single block)
 #define SCAN(C)                                                                                    \
   do {                                                                                             \
+    const uint32_t pair = p.phase_enhance ? 1u : uint32_t (ScanPair<C>::n);                        \
+    const uint32_t nspans = (p.nstrips + pair - 1) / pair;                                         \
+    const dim3 grid ((nspans + kWavesPerBlock - 1) / kWavesPerBlock);                              \
     if (p.phase_enhance) hipLaunchKernelGGL ((scan2400_kernel<C, true>), grid, block, 0, stream, p);  \
     else                 hipLaunchKernelGGL ((scan2400_kernel<C, false>), grid, block, 0, stream, p); \
   } while (0)
