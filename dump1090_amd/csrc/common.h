@@ -114,6 +114,8 @@ struct ScanParams {
   int32_t         mode_ac;
   // demod_2400_AC
   const uint32_t *noise_level;     // [blocks]: (unsigned)((mean_power + sqrt(mean_power - mean_level^2)) * 65535 + 0.5)
+  // demod_2000 / demod_2400 scan kernels: the launch covers strips [strip_begin, strip_end) of the shard (strip_end 0 = nstrips)
+  uint32_t        strip_begin, strip_end;
 };
 
 }  // namespace modes
@@ -139,6 +141,7 @@ struct AcceptParams {
   uint32_t       *changed;       // set to 1 when a delta entry differs from the previous round
   const uint32_t *dirty;         // [nblocks] 1 = the block's entry cache changed since the round before (null: run every block)
   int32_t         mode;          // 2400 or 2000: which demodulator's loop is replayed
+  uint32_t        blk_begin, blk_end;   // the launch covers these blocks of the shard (blk_end 0 = nblocks)
 };
 
 // One completed match window of demod_8000 (ref: src/demod-8000.c:331-420)

@@ -166,9 +166,16 @@ struct modes_engine {
   DevBuf<uint8_t> d8_table, d8_entry;
   DevBuf<int64_t> d8_win_start, d8_small;
   DevBuf<uint32_t> dirty;
-  PinBuf<uint64_t> pin_chunks;                // messages in front of every 1024-strip chunk (read back with the totals)
-  hipStream_t copy_stream = nullptr;          // read-back of one part of the message list while the next part is formed
-  std::vector<hipEvent_t> emit_events;
+  hipStream_t post_stream = nullptr;          // ordered pass and emit of one range of blocks while the next is scanned
+  hipStream_t copy_stream = nullptr;          // read-back of a range's messages
+  std::vector<hipEvent_t> emit_events;        // one per range: its messages are formed
+  std::vector<hipEvent_t> range_events;       // two per range: around its scan
+  size_t last_nm = 0;                         // messages of the last run: what the next run's buffers start with
+  bool have_last_nm = false;
+  // what the host reads once per accept round, in one copy: 32 totals (u64), 64 `changed` words (one per round), the
+  // ICAO cache behind the range's last block
+  DevBuf<uint32_t> rb;
+  PinBuf<uint32_t> pin_rb;
   DevBuf<D8Window> d8_windows, d8_win_packed;
   DevBuf<Record> d8_records, d8_rec_packed;
   PinBuf<D8Window> pin_wins;
@@ -507,12 +514,38 @@ int prepare_dc (modes_engine *e, const void *d_iq, size_t nbytes, const uint16_t
   return MODES_OK;
 }
 
-// The ordered accept pass on the device: fixed-point rounds over the per-block ICAO snapshots, then emit.
-int run_accept_on_device (modes_engine *e, const ScanParams &sp, uint64_t first_sample, hipStream_t stream)
+// Blocks [blk0, blk0 + nblk) of a shard and their strips: the unit the ordered accept pass works on.
+struct RangeView { uint32_t blk0, nblk, strip0, nstrips; };
+
+// Room for `need` messages in d_messages and pin_msgs; the first `keep` stay (the caller has waited for every copy
+// into them).
+int reserve_messages (modes_engine *e, size_t need, size_t keep)
 {
-  const uint32_t B = e->block_samples;
-  const uint32_t nblocks = uint32_t ((sp.nsamples + B - 1) / B);
-  const uint32_t nchunks = (nblocks + 31) / 32;
+  if (need > e->d_messages.cap) {
+    DevBuf<modes_message> bigger;
+    int rc = bigger.reserve (need);
+    if (rc != MODES_OK) return rc;
+    if (keep) HIP_TRY (hipMemcpy (bigger.p, e->d_messages.p, keep * sizeof (modes_message), hipMemcpyDeviceToDevice));
+    e->d_messages.release ();
+    e->d_messages = bigger;
+  }
+  if (need > e->pin_cap) {
+    modes_message *np = nullptr;
+    const size_t want = need + need / 4 + 1024;
+    HIP_TRY (hipHostMalloc (reinterpret_cast<void **> (&np), want * sizeof (modes_message), hipHostMallocDefault));
+    if (keep) memcpy (np, e->pin_msgs, keep * sizeof (modes_message));
+    if (e->pin_msgs) (void) hipHostFree (e->pin_msgs);
+    e->pin_msgs = np; e->pin_cap = want;
+  }
+  return MODES_OK;
+}
+
+constexpr uint32_t kRbTotals = 0, kRbChanged = 64, kRbRounds = 64, kRbCache = kRbChanged + kRbRounds, kRbWords = kRbCache + kIcaoSlots;
+
+int reserve_accept_buffers (modes_engine *e, const ScanParams &sp)
+{
+  const uint32_t nblocks = uint32_t ((sp.nsamples + e->block_samples - 1) / e->block_samples);
+  const uint32_t nchunks = (nblocks + 31) / 32, nsc = (sp.nstrips + 1023) / 1024;
   int rc;
   if ((rc = e->snap_in.reserve (size_t (nblocks) * kIcaoSlots)) != MODES_OK) return rc;
   if ((rc = e->delta.reserve (size_t (nblocks) * kIcaoSlots)) != MODES_OK) return rc;
@@ -521,80 +554,91 @@ int run_accept_on_device (modes_engine *e, const ScanParams &sp, uint64_t first_
   if ((rc = e->acc_counts.reserve (sp.nstrips)) != MODES_OK) return rc;
   if ((rc = e->blk_stats.reserve (size_t (nblocks) * kBlkStats)) != MODES_OK) return rc;
   if ((rc = e->small_u32.reserve (2 * kIcaoSlots + 16)) != MODES_OK) return rc;
+  if ((rc = e->rb.reserve (kRbWords)) != MODES_OK) return rc;
+  if ((rc = e->pin_rb.reserve (kRbWords)) != MODES_OK) return rc;
   if ((rc = e->dirty.reserve (nblocks)) != MODES_OK) return rc;
-  const uint32_t nsc = (sp.nstrips + 1023) / 1024;               // chunks of the strip-count scan
-  if ((rc = e->pin_chunks.reserve (nsc + 1)) != MODES_OK) return rc;
-  uint32_t want_parts = 1;                                        // see the emit step below
-  if (const char *ev = getenv ("MODES_EMIT_PARTS")) { const int v = atoi (ev); if (v >= 1 && uint32_t (v) <= nsc && v <= 16) want_parts = uint32_t (v); }
-  uint32_t *d_cache_in = e->small_u32.p, *d_cache_out = e->small_u32.p + kIcaoSlots, *d_changed = e->small_u32.p + 2 * kIcaoSlots;
+  if ((rc = e->chunk_sum.reserve (nsc + 1)) != MODES_OK) return rc;
+  if ((rc = e->chunk_vp.reserve (nsc + 1)) != MODES_OK) return rc;
+  if ((rc = e->chunk_ovf.reserve (nsc + 1)) != MODES_OK) return rc;
+  return e->offsets.reserve (sp.nstrips);
+}
 
+// The ordered accept pass on the device for one range of blocks whose scan is complete on `stream`: fixed-point rounds
+// over the per-block ICAO snapshots, then emit.  Enters with e->cache = the ICAO cache in front of the range and leaves
+// it as it stands behind the range; statistics add up in e->stats, the range's messages follow the e->pin_n already
+// there.  With `last` clear the read-back of the messages is left in flight on `stream`.
+int accept_range (modes_engine *e, const ScanParams &sp, uint64_t first_sample, hipStream_t stream, const RangeView &rg, bool last,
+                  hipStream_t copy_stream = nullptr, hipEvent_t emitted = nullptr)
+{
+  const uint32_t B = e->block_samples;
+  const uint32_t nblocks = rg.nblk;
+  int rc;
+  uint32_t *d_cache_in = e->small_u32.p, *d_cache_out = e->rb.p + kRbCache, *d_changed = e->rb.p + kRbChanged;
+  uint32_t *snap_in = e->snap_in.p + size_t (rg.blk0) * kIcaoSlots, *delta = e->delta.p + size_t (rg.blk0) * kIcaoSlots;
+  uint32_t *acc_counts = e->acc_counts.p + rg.strip0, *dirty = e->dirty.p + rg.blk0, *blk_stats = e->blk_stats.p + size_t (rg.blk0) * kBlkStats;
+  uint64_t *d_totals = reinterpret_cast<uint64_t *> (e->rb.p + kRbTotals);
+
+  // totals of the range's scan (candidates, valid preambles, overflowed strips)
+  HIP_TRY (launch_count_scan (e->counts.p + rg.strip0, e->vp_counts.p + rg.strip0, rg.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p, d_totals, stream));
   HIP_TRY (hipMemcpyAsync (d_cache_in, e->cache.raw (), kIcaoSlots * sizeof (uint32_t), hipMemcpyHostToDevice, stream));
-  HIP_TRY (hipMemsetAsync (e->delta.p, 0, size_t (nblocks) * kIcaoSlots * sizeof (uint32_t), stream));
-  HIP_TRY (hipMemsetAsync (e->acc_counts.p, 0, size_t (sp.nstrips) * sizeof (uint32_t), stream));
-  HIP_TRY (launch_snap_broadcast (d_cache_in, nblocks, e->snap_in.p, stream));
+  HIP_TRY (hipMemsetAsync (delta, 0, size_t (nblocks) * kIcaoSlots * sizeof (uint32_t), stream));
+  HIP_TRY (hipMemsetAsync (acc_counts, 0, size_t (rg.nstrips) * sizeof (uint32_t), stream));
+  HIP_TRY (hipMemsetAsync (d_changed, 0, kRbRounds * sizeof (uint32_t), stream));
+  HIP_TRY (launch_snap_broadcast (d_cache_in, nblocks, snap_in, stream));
 
   AcceptParams ap;
   memset (&ap, 0, sizeof ap);
   ap.records = e->records.p; ap.counts = e->counts.p; ap.cap = e->cap; ap.nstrips = sp.nstrips;
-  ap.strips_per_block = B / kStrip; ap.nblocks = nblocks; ap.nsamples = sp.nsamples; ap.block_samples = B;
+  ap.strips_per_block = B / kStrip; ap.nblocks = uint32_t ((sp.nsamples + B - 1) / B); ap.nsamples = sp.nsamples; ap.block_samples = B;
+  ap.blk_begin = rg.blk0; ap.blk_end = rg.blk0 + rg.nblk;
   ap.snap_in = e->snap_in.p; ap.delta = e->delta.p; ap.acc_counts = e->acc_counts.p; ap.blk_stats = e->blk_stats.p;
-  ap.vp_bitmap = e->mode == 2400 ? e->vp_bitmap.p : nullptr; ap.changed = d_changed;
+  ap.vp_bitmap = e->mode == 2400 ? e->vp_bitmap.p : nullptr;
   ap.mode = e->mode;
 
-  // Every round queues what the last round needs behind it (snapshots, totals, the cache read-back), so the host waits
-  // once per round and the round that finds nothing changed is already the complete result.
-  uint64_t *d_totals = reinterpret_cast<uint64_t *> (e->d_stats);
-  uint32_t *pin_changed = reinterpret_cast<uint32_t *> (e->pin_small + 32);
+  // Every round queues what the last round needs behind it (snapshots, totals, the cache behind the range), so the host
+  // waits once per round, for one copy, and the round that finds nothing changed is already the complete result.
   uint32_t rounds = 0;
   for (;;) {
-    HIP_TRY (hipMemsetAsync (d_changed, 0, sizeof (uint32_t), stream));
+    const uint32_t slot = rounds % kRbRounds;                    // each round has its own `changed` word
+    if (rounds && slot == 0) HIP_TRY (hipMemsetAsync (d_changed, 0, kRbRounds * sizeof (uint32_t), stream));
+    ap.changed = d_changed + slot;
     HIP_TRY (launch_accept2400 (ap, stream));
-    HIP_TRY (hipMemcpyAsync (pin_changed, d_changed, sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY (hipMemsetAsync (e->dirty.p, 0, size_t (nblocks) * sizeof (uint32_t), stream));
-    HIP_TRY (launch_snapshots (e->delta.p, nblocks, d_cache_in, e->chunk_last.p, e->chunk_entry.p, e->snap_in.p, d_cache_out, e->dirty.p, stream));
+    HIP_TRY (launch_snapshots (delta, nblocks, d_cache_in, e->chunk_last.p, e->chunk_entry.p, snap_in, d_cache_out, dirty, stream));
     ap.dirty = e->dirty.p;                                      // from the second round on
     // totals of accepted messages and the block statistics, read back together with the scan's totals
-    HIP_TRY (launch_count_scan (e->acc_counts.p, e->vp_counts.p, sp.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p, d_totals + 4, stream));
-    HIP_TRY (launch_blk_stats_sum (e->blk_stats.p, nblocks, e->d_stats + 8, stream));
-    HIP_TRY (hipMemcpyAsync (e->pin_small, d_totals, 32 * sizeof (unsigned long long), hipMemcpyDeviceToHost, stream));
-    HIP_TRY (hipMemcpyAsync (e->pin_cache, d_cache_out, kIcaoSlots * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
-    if (want_parts > 1) HIP_TRY (hipMemcpyAsync (e->pin_chunks.p, e->chunk_sum.p, size_t (nsc) * sizeof (uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY (launch_count_scan (acc_counts, e->vp_counts.p + rg.strip0, rg.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p, d_totals + 4, stream));
+    HIP_TRY (launch_blk_stats_sum (blk_stats, nblocks, reinterpret_cast<unsigned long long *> (d_totals + 8), stream));
+    HIP_TRY (hipMemcpyAsync (e->pin_rb.p, e->rb.p, kRbWords * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
     HIP_TRY (hipStreamSynchronize (stream));
     rounds++;
-    if (!*pin_changed) break;
+    if (!e->pin_rb.p[kRbChanged + slot]) break;
     // a write set can only change because an earlier block's did: block k is final after round k + 1 at the latest
     if (rounds > nblocks + 2) return fail (MODES_E_HIP, "accept pass did not reach its fixed point in %u rounds", rounds);
   }
-  e->stats.replay_rounds = rounds;
-  e->accept_passes++;
-  memcpy (e->cache.raw (), e->pin_cache, kIcaoSlots * sizeof (uint32_t));
-  (void) hipEventElapsedTime (&e->kernel_ms[0], e->ev[0], e->ev[1]);
-  e->kernel_ms[1] = 0;
-  const unsigned long long *st = e->pin_small, *tot = e->pin_small + 4, *sum = e->pin_small + 8;
+  e->stats.replay_rounds += rounds;
+  memcpy (e->cache.raw (), e->pin_rb.p + kRbCache, kIcaoSlots * sizeof (uint32_t));
+  const unsigned long long *st = reinterpret_cast<const unsigned long long *> (e->pin_rb.p + kRbTotals), *tot = st + 4, *sum = st + 8;
   if (st[2]) return fail (MODES_E_OVERFLOW, "%llu strips overflowed their candidate slots (cap %u)", st[2], e->cap);
-  e->stats.valid_preamble = st[1];
-  e->stats.candidates = st[0];
+  e->stats.candidates += st[0];
   const size_t nm = size_t (tot[0]);
-  e->stats.demodulated = sum[kStDemodulated]; e->stats.out_of_phase = sum[kStOutOfPhase];
-  e->stats.CRC_good = sum[kStGood]; e->stats.CRC_bad = sum[kStBad];
-  e->stats.CRC_single_bit_fix = sum[kStFix1]; e->stats.CRC_two_bits_fix = sum[kStFix2];
-  e->stats.CRC_fixed = sum[kStFix1] + sum[kStFix2];
-  e->stats.demod_rejected_unknown = sum[kStUnknown];
-  e->stats.demod_modeac = sum[kStModeAC];
-  if (e->mode == 2000) e->stats.valid_preamble = sum[kStVp];      // every valid preamble is a record there
-  else e->stats.valid_preamble -= sum[kStSkippedVp];
+  e->stats.demodulated += sum[kStDemodulated]; e->stats.out_of_phase += sum[kStOutOfPhase];
+  e->stats.CRC_good += sum[kStGood]; e->stats.CRC_bad += sum[kStBad];
+  e->stats.CRC_single_bit_fix += sum[kStFix1]; e->stats.CRC_two_bits_fix += sum[kStFix2];
+  e->stats.CRC_fixed += sum[kStFix1] + sum[kStFix2];
+  e->stats.demod_rejected_unknown += sum[kStUnknown];
+  e->stats.demod_modeac += sum[kStModeAC];
+  if (e->mode == 2000) e->stats.valid_preamble += sum[kStVp];     // every valid preamble is a record there
+  else e->stats.valid_preamble += st[1] - sum[kStSkippedVp];
   if (sum[kStAccepted] != nm) return fail (MODES_E_HIP, "accepted-count mismatch (%llu vs %zu)", (unsigned long long) sum[kStAccepted], nm);
 
-  e->in_pinned = true;
-  e->pin_n = nm;
+  const size_t base = e->pin_n;
   if (nm) {
-    if ((rc = e->d_messages.reserve (nm)) != MODES_OK) return rc;
-    if (nm > e->pin_cap) {
-      if (e->pin_msgs) (void) hipHostFree (e->pin_msgs);
-      e->pin_msgs = nullptr; e->pin_cap = 0;
-      const size_t want = nm + nm / 4 + 1024;
-      HIP_TRY (hipHostMalloc (reinterpret_cast<void **> (&e->pin_msgs), want * sizeof (modes_message), hipHostMallocDefault));
-      e->pin_cap = want;
+    if (base + nm > e->d_messages.cap || base + nm > e->pin_cap) {
+      // the list outgrew what the run set out with: wait for the read-backs in flight, then move to larger buffers
+      if (base) HIP_TRY (hipStreamSynchronize (copy_stream ? copy_stream : stream));
+      const uint32_t nb_all = ap.nblocks, nb_done = rg.blk0 + rg.nblk;
+      const size_t guess = size_t (double (base + nm) * double (nb_all) / double (nb_done) * 1.25) + 1024;
+      if ((rc = reserve_messages (e, guess, base)) != MODES_OK) return rc;
     }
     EmitParams ep;
     memset (&ep, 0, sizeof ep);
@@ -603,37 +647,112 @@ int run_accept_on_device (modes_engine *e, const ScanParams &sp, uint64_t first_
     ep.iq = sp.iq; ep.nsamples = sp.nsamples; ep.navail = sp.navail; ep.halo = sp.halo; ep.ov = sp.ov;
     ep.block_samples = sp.block_samples; ep.conv = sp.conv; ep.lut256 = sp.lut256;
     ep.first_sample = first_sample; ep.sample_rate = e->cfg.sample_rate;
-    ep.messages = e->d_messages.p;
+    ep.messages = e->d_messages.p + base;             // offsets[] count from the range's first strip
     ep.mode = e->mode;
-    HIP_TRY (launch_strip_offsets (e->acc_counts.p, sp.nstrips, e->chunk_sum.p, e->offsets.p, stream));
-    // The list can be formed in parts (whole 1024-strip chunks, whose first message index the host already holds), one
-    // part travelling to the host on a second stream while the next is formed (MODES_EMIT_PARTS=n).
-    // Off unless asked for: four parts measure 3-5 % faster on 0.4-1.3 M messages, but one run in three loses a
-    // millisecond when the read-back on the second stream takes a slower copy path.
-    const uint32_t parts = want_parts;
-    if (parts > 1) {
-      if (!e->copy_stream) HIP_TRY (hipStreamCreateWithFlags (&e->copy_stream, hipStreamNonBlocking));
-      while (e->emit_events.size () < parts) { hipEvent_t ev; HIP_TRY (hipEventCreateWithFlags (&ev, hipEventDisableTiming)); e->emit_events.push_back (ev); }
+    ep.strip_begin = rg.strip0; ep.strip_end = rg.strip0 + rg.nstrips;
+    HIP_TRY (launch_strip_offsets (acc_counts, rg.nstrips, e->chunk_sum.p, e->offsets.p + rg.strip0, stream));
+    HIP_TRY (launch_emit2400 (ep, stream));
+    hipStream_t cs = stream;
+    if (copy_stream) {                                // the read-back does not hold up the next range's pass
+      HIP_TRY (hipEventRecord (emitted, stream));
+      HIP_TRY (hipStreamWaitEvent (copy_stream, emitted, 0));
+      cs = copy_stream;
     }
-    const modes_message *d_msgs = static_cast<const modes_message *> (e->d_messages.p);
-    for (uint32_t r = 0; r < parts; r++) {
-      const uint32_t c0 = uint32_t (uint64_t (nsc) * r / parts), c1 = uint32_t (uint64_t (nsc) * (r + 1) / parts);
-      ep.strip_begin = c0 * 1024u;
-      ep.strip_end = c1 * 1024u < sp.nstrips ? c1 * 1024u : sp.nstrips;
-      const size_t m0 = (parts > 1 && c0) ? size_t (e->pin_chunks.p[c0]) : 0, m1 = (parts > 1 && c1 < nsc) ? size_t (e->pin_chunks.p[c1]) : nm;
-      HIP_TRY (launch_emit2400 (ep, stream));
-      if (m1 <= m0) continue;
-      hipStream_t cs = stream;
-      if (parts > 1) {
-        HIP_TRY (hipEventRecord (e->emit_events[r], stream));
-        HIP_TRY (hipStreamWaitEvent (e->copy_stream, e->emit_events[r], 0));
-        cs = e->copy_stream;
-      }
-      HIP_TRY (hipMemcpyAsync (e->pin_msgs + m0, d_msgs + m0, (m1 - m0) * sizeof (modes_message), hipMemcpyDeviceToHost, cs));
-    }
-    HIP_TRY (hipStreamSynchronize (stream));
-    if (parts > 1) HIP_TRY (hipStreamSynchronize (e->copy_stream));
+    HIP_TRY (hipMemcpyAsync (e->pin_msgs + base, e->d_messages.p + base, nm * sizeof (modes_message), hipMemcpyDeviceToHost, cs));
+    e->pin_n = base + nm;
   }
+  e->in_pinned = true;
+  if (last) {
+    HIP_TRY (hipStreamSynchronize (stream));
+    if (copy_stream) HIP_TRY (hipStreamSynchronize (copy_stream));
+  }
+  return MODES_OK;
+}
+
+// The whole shard as one range, behind a scan already queued on `stream`.
+int run_accept_on_device (modes_engine *e, const ScanParams &sp, uint64_t first_sample, hipStream_t stream, bool scan_timed = true)
+{
+  int rc = reserve_accept_buffers (e, sp);
+  if (rc != MODES_OK) return rc;
+  const uint32_t nblocks = uint32_t ((sp.nsamples + e->block_samples - 1) / e->block_samples);
+  const RangeView all = { 0, nblocks, 0, sp.nstrips };
+  e->pin_n = 0;
+  rc = accept_range (e, sp, first_sample, stream, all, true);
+  e->accept_passes++;
+  e->kernel_ms[0] = e->kernel_ms[1] = 0;
+  if (scan_timed) (void) hipEventElapsedTime (&e->kernel_ms[0], e->ev[0], e->ev[1]);     // ev[] lie around this run's scan
+  return rc;
+}
+
+// A long shard in ranges of blocks: the scan of range r + 1 runs (on the caller's stream) while the ordered pass, the
+// emit and the read-back of range r run on a second stream.  The ICAO cache is handed from range to range like it is
+// from block to block; each range's messages are final when its pass ends, so their copy to the host overlaps the
+// scan as well.  Same records, same order, same list as the single pass.
+int scan_and_accept_in_ranges (modes_engine *e, ScanParams &sp, uint64_t first_sample, hipStream_t stream, uint32_t nranges)
+{
+  const uint32_t B = e->block_samples, spb = B / kStrip;
+  const uint32_t nblocks = uint32_t ((sp.nsamples + B - 1) / B);
+  int rc = reserve_accept_buffers (e, sp);
+  if (rc != MODES_OK) return rc;
+  if (!e->post_stream) HIP_TRY (hipStreamCreateWithFlags (&e->post_stream, hipStreamNonBlocking));
+  if (!e->copy_stream) HIP_TRY (hipStreamCreateWithFlags (&e->copy_stream, hipStreamNonBlocking));
+  while (e->emit_events.size () < size_t (nranges)) {
+    hipEvent_t ev;
+    HIP_TRY (hipEventCreateWithFlags (&ev, hipEventDisableTiming));
+    e->emit_events.push_back (ev);
+  }
+  while (e->range_events.size () < 2 * size_t (nranges)) {
+    hipEvent_t ev;
+    HIP_TRY (hipEventCreate (&ev));
+    e->range_events.push_back (ev);
+  }
+  if (e->last_nm) if ((rc = reserve_messages (e, e->last_nm + e->last_nm / 8 + 1024, 0)) != MODES_OK) return rc;
+  std::vector<RangeView> rgs;
+  // Ranges shrink towards the end (weights R, R-1, .. 1): what is left to do when the last scan ends -- the last
+  // range's pass, emit and read-back -- is what the overlap cannot hide.
+  const bool taper = !getenv ("MODES_RANGES_EVEN");
+  const uint64_t wsum = taper ? uint64_t (nranges) * (nranges + 1) / 2 : nranges;
+  auto cut = [&] (uint32_t r) -> uint32_t {       // first block of range r
+    const uint64_t w = taper ? uint64_t (r) * (2 * nranges - r + 1) / 2 : r;
+    return uint32_t (uint64_t (nblocks) * w / wsum);
+  };
+  for (uint32_t r = 0; r < nranges; r++) {
+    const uint32_t b0 = cut (r), b1 = r + 1 == nranges ? nblocks : cut (r + 1);
+    const uint32_t s0 = b0 * spb, s1 = b1 * spb < sp.nstrips ? b1 * spb : sp.nstrips;
+    if (b1 > b0) rgs.push_back (RangeView { b0, b1 - b0, s0, s1 - s0 });
+  }
+  nranges = uint32_t (rgs.size ());
+  auto queue_scan = [&] (uint32_t r) -> hipError_t {
+    ScanParams q = sp;
+    q.strip_begin = rgs[r].strip0; q.strip_end = rgs[r].strip0 + rgs[r].nstrips;
+    hipError_t he = hipEventRecord (e->range_events[2 * r], stream);
+    if (he == hipSuccess) he = e->mode == 2000 ? launch_scan2000 (q, stream) : launch_scan2400 (q, stream);
+    if (he == hipSuccess) he = hipEventRecord (e->range_events[2 * r + 1], stream);
+    return he;
+  };
+  // on any way out nothing of this run is left in flight on either stream
+  struct Drain {
+    modes_engine *e; hipStream_t s;
+    ~Drain () { (void) hipStreamSynchronize (e->post_stream); (void) hipStreamSynchronize (e->copy_stream); (void) hipStreamSynchronize (s); }
+  } drain = { e, stream };
+  e->pin_n = 0;
+  HIP_TRY (queue_scan (0));
+  e->scan_launches++;
+  for (uint32_t r = 0; r < nranges; r++) {
+    if (r + 1 < nranges) HIP_TRY (queue_scan (r + 1));
+    else HIP_TRY (launch_tail (sp, sp.nsamples, e->tail.p + e->tail_half * ((e->ov + 7u) & ~7u), stream));   // what a following shard needs as d_halo
+    HIP_TRY (hipStreamWaitEvent (e->post_stream, e->range_events[2 * r + 1], 0));
+    if ((rc = accept_range (e, sp, first_sample, e->post_stream, rgs[r], r + 1 == nranges, e->copy_stream, e->emit_events[r])) != MODES_OK) return rc;
+  }
+  HIP_TRY (hipStreamSynchronize (stream));
+  e->accept_passes++;
+  float ms = 0;
+  for (uint32_t r = 0; r < nranges; r++) {
+    float t = 0;
+    (void) hipEventElapsedTime (&t, e->range_events[2 * r], e->range_events[2 * r + 1]);
+    ms += t;
+  }
+  e->kernel_ms[0] = ms; e->kernel_ms[1] = 0;
   return MODES_OK;
 }
 
@@ -700,11 +819,13 @@ void modes_engine_destroy (modes_engine *e)
   e->d8_trig.release (); e->d8_amb.release (); e->d8_off.release (); e->d8_p0.release (); e->d8_mx.release ();
   e->d8_win_count.release (); e->d8_chunk_rec.release (); e->d8_announce.release (); e->d8_table.release (); e->d8_entry.release ();
   e->d8_win_start.release (); e->d8_small.release (); e->d8_windows.release (); e->d8_win_packed.release ();
-  e->d8_records.release (); e->d8_rec_packed.release (); e->dirty.release (); e->pin_chunks.release ();
+  e->d8_records.release (); e->d8_rec_packed.release (); e->dirty.release (); e->rb.release (); e->pin_rb.release ();
   e->d8_dprev.release (); e->d8_dnext.release (); e->pin_d8.release ();
   e->d_fields.release (); e->pin_fields.release ();
+  if (e->post_stream) (void) hipStreamDestroy (e->post_stream);
   if (e->copy_stream) (void) hipStreamDestroy (e->copy_stream);
   for (hipEvent_t ev : e->emit_events) if (ev) (void) hipEventDestroy (ev);
+  for (hipEvent_t ev : e->range_events) if (ev) (void) hipEventDestroy (ev);
   e->pin_wins.release (); e->pin_recs.release (); e->pin_bits.release (); e->pin_counts.release ();
   for (hipEvent_t ev : e->d8_events) if (ev) (void) hipEventDestroy (ev);
   if (e->tabs.short_tab) (void) hipFree (e->tabs.short_tab);
@@ -789,11 +910,32 @@ static int run_device_inner (modes_engine *e, const void *d_iq, size_t nbytes, u
 static int scan_and_decode (modes_engine *e, ScanParams &sp, uint64_t first_sample, hipStream_t stream)
 {
   int rc;
+  const bool device_accept = !e->cfg.host_replay && !e->cfg.phase_enhance;
+  if (device_accept) {
+    // What the ranges hide is the read-back of the message list (the ordered pass and the emit are latency bound and
+    // fill the wave slots the scan would use, so running them beside the scan gains nothing): three or four ranges
+    // for a long shard, none for a short one or when the last run's list was small.
+    const uint32_t nblocks = uint32_t ((sp.nsamples + e->block_samples - 1) / e->block_samples);
+    uint32_t nranges = nblocks >= 1024 ? (e->mode == 2000 ? 4u : 3u) : nblocks >= 512 ? 2u : 1u;
+    if (e->have_last_nm && e->last_nm < 65536) nranges = 1;
+    if (const char *ev = getenv ("MODES_RANGES")) { const int v = atoi (ev); if (v >= 1 && v <= 64) nranges = uint32_t (v) < nblocks ? uint32_t (v) : nblocks; }
+    if (nranges > 1 && sp.block_strips) {
+      rc = scan_and_accept_in_ranges (e, sp, first_sample, stream, nranges);
+      if (rc == MODES_OK) { e->last_sp = sp; e->last_first_sample = first_sample; e->have_scan = true; e->last_nm = e->pin_n; e->have_last_nm = true; }
+      return rc;
+    }
+  }
   HIP_TRY (hipEventRecord (e->ev[0], stream));
   HIP_TRY (e->mode == 2000 ? launch_scan2000 (sp, stream) : launch_scan2400 (sp, stream));
   e->scan_launches++;
   HIP_TRY (hipEventRecord (e->ev[1], stream));
   HIP_TRY (launch_tail (sp, sp.nsamples, e->tail.p + e->tail_half * ((e->ov + 7u) & ~7u), stream));   // what a following shard needs as d_halo
+
+  if (device_accept) {
+    rc = run_accept_on_device (e, sp, first_sample, stream);
+    if (rc == MODES_OK) { e->last_sp = sp; e->last_first_sample = first_sample; e->have_scan = true; e->last_nm = e->pin_n; e->have_last_nm = true; }
+    return rc;
+  }
 
   // totals, then compact the per-strip slots into one ordered list
   const uint32_t nchunks = (sp.nstrips + 1023) / 1024;
@@ -804,11 +946,6 @@ static int scan_and_decode (modes_engine *e, ScanParams &sp, uint64_t first_samp
   uint64_t *d_totals = reinterpret_cast<uint64_t *> (e->d_stats);
   HIP_TRY (launch_count_scan (e->counts.p, e->vp_counts.p, sp.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p,
                               d_totals, stream));
-  if (!e->cfg.host_replay && !e->cfg.phase_enhance) {
-    rc = run_accept_on_device (e, sp, first_sample, stream);
-    if (rc == MODES_OK) { e->last_sp = sp; e->last_first_sample = first_sample; e->have_scan = true; }
-    return rc;
-  }
 
   unsigned long long st[3];
   HIP_TRY (hipMemcpyAsync (st, d_totals, sizeof st, hipMemcpyDeviceToHost, stream));
@@ -1233,11 +1370,8 @@ int modes_engine_rerun_accept (modes_engine *e, void *stream_v)
   e->in_pinned = false; e->pin_n = 0;
   memset (&e->stats, 0, sizeof e->stats);
   e->stats.scan_retries = retries;
-  // the totals of the scan are formed again from the per-strip counts (run_accept_on_device reads them with its own)
-  uint64_t *d_totals = reinterpret_cast<uint64_t *> (e->d_stats);
-  HIP_TRY (launch_count_scan (e->counts.p, e->vp_counts.p, e->last_sp.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p, d_totals, stream));
   (void) cand;
-  return run_accept_on_device (e, e->last_sp, e->last_first_sample, stream);
+  return run_accept_on_device (e, e->last_sp, e->last_first_sample, stream, false);
 }
 
 int modes_engine_set_d8_state (modes_engine *e, const modes_d8_state *in)

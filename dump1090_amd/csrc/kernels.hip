@@ -103,7 +103,8 @@ void scan2400_kernel (const ScanParams p)
     s_lut[threadIdx.x] = p.lut256[threadIdx.x];
     __syncthreads ();
   }
-  const uint32_t strip = (blockIdx.x * kWavesPerBlock + wv) * kPair;         // first strip of this wave's span
+  const uint32_t strip = p.strip_begin + (blockIdx.x * kWavesPerBlock + wv) * kPair;   // first strip of this wave's span
+  const uint32_t strip_end = p.strip_end ? p.strip_end : p.nstrips;
 #pragma unroll
   for (int h = 0; h < kPair; h++) w.vp[64 * h + lane] = 0;
 
@@ -113,12 +114,12 @@ void scan2400_kernel (const ScanParams p)
   const uint32_t sbL0 = c_single_bit[bl], sbL1 = bl < 48 ? c_single_bit[64 + bl] : 0u, sbS = bl < 56 ? c_single_bit[56 + bl] : 0u;
 
   // ---- stage A: magnitudes V[G0 .. G0 + 4 spans + kLook2400) into LDS, staged by the whole workgroup in two goes ----
-  const long long G0 = (long long) blockIdx.x * kGroupSpan;
+  const long long G0 = (long long) p.strip_begin * kStrip + (long long) blockIdx.x * kGroupSpan;
   const long long s0 = G0 - (long long) (CONV == kConvMagU16 ? 0u : p.ov);   // sample index of V[G0] (may be < 0)
   stage_tile_pos<CONV, kStageHalf, 64 * kWavesPerBlock> (s_tile + kTileLead, s_lut, p, s0, int (threadIdx.x));
   stage_tile_pos<CONV, kStageHalf + kLook2400, 64 * kWavesPerBlock> (s_tile + kTileLead + kStageHalf, s_lut, p, s0 + kStageHalf, int (threadIdx.x));
   __syncthreads ();
-  if (strip >= p.nstrips) return;
+  if (strip >= strip_end) return;
   const long long P0 = (long long) strip * kStrip;
   const uint16_t *V = s_tile + kTileLead + wv * kSpan;
 
@@ -397,7 +398,7 @@ void scan2400_kernel (const ScanParams p)
 
 #pragma unroll
   for (int h = 0; h < kPair; h++) {
-    if (strip + h >= p.nstrips) break;
+    if (strip + h >= strip_end) break;
     if (p.vp_bitmap) reinterpret_cast<uint32_t *> (p.vp_bitmap)[size_t (strip + h) * (kStrip / 32) + lane] = w.vp[64 * h + lane];
     if (lane == 0) {      // per-strip results only: no contended atomics
       p.counts[strip + h] = overflow ? 0xFFFFFFFFu : nrec[h];
@@ -490,43 +491,26 @@ void chunk_sums_kernel (const uint32_t *counts, const uint32_t *vp_counts, uint3
   }
 }
 
-// single workgroup: exclusive scan of chunk sums in place; totals go to totals[0..2] = records, valid preambles, overflowed strips
-__global__ __launch_bounds__ (1024)
+// one wave: exclusive scan of chunk sums in place; totals go to totals[0..2] = records, valid preambles, overflowed strips.
+// (No barriers: the launch often shares the GPU with a scan kernel, where a 16-wave workgroup waits long for a CU.)
+__global__ __launch_bounds__ (64)
 void scan_chunk_sums_kernel (uint64_t *chunk_sum, const uint64_t *chunk_vp, const uint64_t *chunk_ovf, uint32_t nchunks,
                              uint64_t *totals)
 {
-  __shared__ uint64_t buf[1024];
-  __shared__ uint64_t carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads ();
-  uint64_t vp = 0, ovf = 0;
-  for (uint32_t base = 0; base < nchunks; base += 1024) {
-    const uint32_t i = base + threadIdx.x;
+  __builtin_amdgcn_s_setprio (3);
+  const int lane = threadIdx.x;
+  uint64_t carry = 0, vp = 0, ovf = 0;
+  for (uint32_t base = 0; base < nchunks; base += 64) {
+    const uint32_t i = base + lane;
     const uint64_t v = i < nchunks ? chunk_sum[i] : 0;
     if (i < nchunks) { vp += chunk_vp[i]; ovf += chunk_ovf[i]; }
-    buf[threadIdx.x] = v;
-    __syncthreads ();
-    for (int d = 1; d < 1024; d <<= 1) {
-      const uint64_t o = threadIdx.x >= (unsigned) d ? buf[threadIdx.x - d] : 0;
-      __syncthreads ();
-      buf[threadIdx.x] += o;
-      __syncthreads ();
-    }
-    if (i < nchunks) chunk_sum[i] = carry + buf[threadIdx.x] - v;
-    __syncthreads ();
-    if (threadIdx.x == 1023) carry += buf[1023];
-    __syncthreads ();
+    uint64_t incl = v;
+    for (int d = 1; d < 64; d <<= 1) { const uint64_t o = __shfl_up (incl, d, 64); if (lane >= d) incl += o; }
+    if (i < nchunks) chunk_sum[i] = carry + incl - v;
+    carry += __shfl (incl, 63, 64);
   }
-  // reduce vp / ovf over the workgroup
-  buf[threadIdx.x] = vp;
-  __syncthreads ();
-  for (int d = 512; d >= 1; d >>= 1) { if (threadIdx.x < (unsigned) d) buf[threadIdx.x] += buf[threadIdx.x + d]; __syncthreads (); }
-  const uint64_t vp_total = buf[0];
-  __syncthreads ();
-  buf[threadIdx.x] = ovf;
-  __syncthreads ();
-  for (int d = 512; d >= 1; d >>= 1) { if (threadIdx.x < (unsigned) d) buf[threadIdx.x] += buf[threadIdx.x + d]; __syncthreads (); }
-  if (threadIdx.x == 0) { totals[0] = carry; totals[1] = vp_total; totals[2] = buf[0]; }
+  for (int d = 32; d >= 1; d >>= 1) { vp += __shfl_xor (vp, d, 64); ovf += __shfl_xor (ovf, d, 64); }
+  if (lane == 0) { totals[0] = carry; totals[1] = vp; totals[2] = ovf; }
 }
 
 // one wave per strip: offsets[strip] = chunk base + scan inside the chunk; copies the strip's records
@@ -703,17 +687,21 @@ struct AcceptLds {
 
 __device__ __forceinline__ uint32_t rdlane (uint32_t v, int l) { return uint32_t (__builtin_amdgcn_readlane (int (v), l)); }
 
+// One wave per workgroup and 5 KiB of LDS: the pass of one range of blocks runs while the next range is scanned, and a
+// workgroup this small finds room on a CU the scan kernel has filled.
 template <int MODE>
-__global__ __launch_bounds__ (256)
+__global__ __launch_bounds__ (64)
 void accept_kernel (const AcceptParams p)
 {
-  __shared__ AcceptLds lds[4];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const uint32_t blk = blockIdx.x * 4 + wv;
-  if (blk >= p.nblocks) return;
+  __shared__ AcceptLds lds[1];
+  const int lane = threadIdx.x & 63, wv = 0;
+  const uint32_t blk = p.blk_begin + blockIdx.x;
+  if (blk >= (p.blk_end ? p.blk_end : p.nblocks)) return;
   if (p.dirty && !p.dirty[blk]) return;                      // same entry cache as in the round before: same results
+  __builtin_amdgcn_s_setprio (3);                            // the pass is latency bound and often shares the GPU with a scan
   AcceptLds &w = lds[wv];
-  for (int i = lane; i < int (kIcaoSlots); i += 64) w.cache[i] = p.snap_in[size_t (blk) * kIcaoSlots + i];
+  const uint32_t *entry = p.snap_in + size_t (blk) * kIcaoSlots;     // the cache as the block starts with it
+  for (int i = lane; i < int (kIcaoSlots); i += 64) w.cache[i] = entry[i];
   if (lane < int (kIcaoSlots / 32)) w.written[lane] = 0;
   if (lane < kBlkStats) w.counter[lane] = 0;
   __builtin_amdgcn_s_waitcnt (0xc07f);
@@ -738,6 +726,33 @@ void accept_kernel (const AcceptParams p)
   }
   __builtin_amdgcn_s_waitcnt (0xc07f);
   __builtin_amdgcn_wave_barrier ();
+  // A block whose entry cache changed repeats itself all the same unless the change shows where a record looks: every
+  // decision and score reads the cache either at a slot the block wrote before (same history, same value) or as the block
+  // found it.  Record.flags bit 1 keeps "entry[slot] == address" from the block's last pass; if it holds for every record
+  // under the new entry cache, the last pass's results stand.
+  if (p.dirty) {
+    bool differs = false;
+    for (uint32_t base = 0; base < total; base += 64) {
+      const uint32_t g = base + lane;
+      const bool have = g < total;
+      uint32_t sl = 0;
+#pragma unroll
+      for (uint32_t step = 32; step >= 1; step >>= 1)
+        if (sl + step < nst && w.prefix[sl + step] <= g) sl += step;
+      const Record *rp = p.records + size_t (first_strip + sl) * p.cap + (have ? g - w.prefix[sl] : 0u);
+      Record r;
+      if (have) { const uint4 *s4 = reinterpret_cast<const uint4 *> (rp); *reinterpret_cast<uint4 *> (&r) = s4[0]; *(reinterpret_cast<uint4 *> (&r) + 1) = s4[1]; }
+      else memset (&r, 0, sizeof r);
+      uint32_t aa = (uint32_t (r.msg[1]) << 16) | (uint32_t (r.msg[2]) << 8) | r.msg[3];
+      if (r.nerr >= 1 && r.bit0 >= 8 && r.bit0 <= 31) aa ^= 1u << (31 - r.bit0);
+      if (r.nerr >= 2 && r.bit1 >= 8 && r.bit1 <= 31) aa ^= 1u << (31 - r.bit1);
+      const uint32_t test_addr = (r.cls == kClsAP || r.cls == kClsAP2) ? r.crc : aa;
+      const uint32_t ev = w.cache[icao_hash (test_addr)];         // nothing written yet: still the entry cache
+      const bool eq = ev != 0 && ev == test_addr;
+      if (have && eq != bool ((r.flags >> 1) & 1)) differs = true;
+    }
+    if (!__ballot (differs)) return;
+  }
   {
     for (uint32_t base = 0; base < total; base += 64) {
       const uint32_t g = base + lane;
@@ -779,8 +794,9 @@ void accept_kernel (const AcceptParams p)
       const uint32_t skip_len = modea ? 50u                                             // ref: src/demod-2000.c:698
                               : MODE == 2000 ? 2u * (8u + r.pad[2]) - 1u                // ref: src/demod-2000.c:997
                                              : uint32_t (msg_bits_for_df (r.df)) * 12 / 5;   // ref: src/demod-2400.c:514
-      const uint32_t c0 = w.cache[slot];
+      const uint32_t c0 = w.cache[slot], e0 = entry[slot];
       bool known = have && c0 != 0 && c0 == test_addr;
+      const bool eq_entry = e0 != 0 && e0 == test_addr;
 
       // --- which records can change anything: acceptable now, or their slot is written inside this batch ---
       bool touched = false;
@@ -848,9 +864,9 @@ void accept_kernel (const AcceptParams p)
       st_fix1  += __popcll (__ballot (is_acc && ebits == 1));
       st_fix2  += __popcll (__ballot (is_acc && ebits == 2));
       if (is_acc) atomicAdd (&w.accn[sl], 1u);
-      // write back: flags bit0 = accepted, pad[0..1] = score
+      // write back: flags bit0 = accepted, bit1 = address found in the entry cache, pad[0..1] = score
       if (have) {
-        const uint8_t nf = is_acc ? 1 : 0;
+        const uint8_t nf = (is_acc ? 1 : 0) | (eq_entry ? 2 : 0);
         const int16_t sc16 = int16_t (score);
         if (r.flags != nf || *reinterpret_cast<const int16_t *> (r.pad) != sc16) {
           rp->flags = nf;
@@ -909,12 +925,13 @@ constexpr int kSnapChunk = 32;
 
 // last write per (chunk of blocks, slot)
 __global__ __launch_bounds__ (256)
-void snap_chunk_last_kernel (const uint32_t *delta, uint32_t nblocks, uint32_t *chunk_last)
+void snap_chunk_last_kernel (const uint32_t *delta, uint32_t nblocks, uint32_t *chunk_last, uint32_t *dirty)
 {
   const uint32_t s = blockIdx.x * 256 + threadIdx.x, chunk = blockIdx.y;
   if (s >= kIcaoSlots) return;
   uint32_t v = 0;
   const uint32_t b0 = chunk * kSnapChunk, b1 = min (b0 + kSnapChunk, nblocks);
+  if (s < kSnapChunk && b0 + s < b1) dirty[b0 + s] = 0u;             // snap_fill_kernel, next in the stream, marks the blocks to repeat
   for (uint32_t b = b0; b < b1; b++) { const uint32_t d = delta[size_t (b) * kIcaoSlots + s]; if (d & kDeltaWritten) v = d; }
   chunk_last[size_t (chunk) * kIcaoSlots + s] = v;
 }
@@ -1107,6 +1124,17 @@ void emit2400_kernel (const EmitParams p)
             }
             if (x < slen) acc += u64 (m * m);
           }
+        } else if (lut && n0 >= 0 && uint64_t (n0) + 320 <= p.nsamples && uint64_t (n0) % p.block_samples + 320 <= p.block_samples) {
+          // the byte table inside one block: sample i of the block is the table's value for byte i of the block
+          const uint8_t *src = p.iq + uint64_t (n0) / p.block_samples * 2 * p.block_samples + uint64_t (n0) % p.block_samples;
+          uint32_t raw[5];
+#pragma unroll
+          for (int q = 0; q < 5; q++) raw[q] = src[lane + 64 * q];
+#pragma unroll
+          for (int q = 0; q < 5; q++) {
+            const uint32_t m = p.lut256[raw[q]];
+            if (lane + 64 * q < slen) acc += u64 (m * m);
+          }
         } else {
           for (int q = lane; q < slen; q += 64) {
             const uint32_t m = mag_of_V<CONV> (p.iq, CONV == kConvMagU16 ? p.navail : p.nsamples, p.halo, p.ov, p.block_samples, p.lut256, (long long) P + 19 + q);
@@ -1263,7 +1291,7 @@ hipError_t launch_scan2400 (const ScanParams &p, hipStream_t stream)
 #define SCAN(C)                                                                                    \
   do {                                                                                             \
     const uint32_t pair = p.phase_enhance ? 1u : uint32_t (ScanPair<C>::n);                        \
-    const uint32_t nspans = (p.nstrips + pair - 1) / pair;                                         \
+    const uint32_t nspans = ((p.strip_end ? p.strip_end : p.nstrips) - p.strip_begin + pair - 1) / pair; \
     const dim3 grid ((nspans + kWavesPerBlock - 1) / kWavesPerBlock);                              \
     if (p.phase_enhance) hipLaunchKernelGGL ((scan2400_kernel<C, true>), grid, block, 0, stream, p);  \
     else                 hipLaunchKernelGGL ((scan2400_kernel<C, false>), grid, block, 0, stream, p); \
@@ -1328,7 +1356,7 @@ hipError_t launch_count_scan (const uint32_t *counts, const uint32_t *vp_counts,
   if (nstrips == 0) return hipSuccess;
   const uint32_t nchunks = (nstrips + kScanChunk - 1) / kScanChunk;
   hipLaunchKernelGGL (chunk_sums_kernel, dim3 (nchunks), dim3 (256), 0, stream, counts, vp_counts, nstrips, chunk_sum, chunk_vp, chunk_ovf);
-  hipLaunchKernelGGL (scan_chunk_sums_kernel, dim3 (1), dim3 (1024), 0, stream, chunk_sum, chunk_vp, chunk_ovf, nchunks, totals);
+  hipLaunchKernelGGL (scan_chunk_sums_kernel, dim3 (1), dim3 (64), 0, stream, chunk_sum, chunk_vp, chunk_ovf, nchunks, totals);
   return hipGetLastError ();
 }
 
@@ -1370,9 +1398,10 @@ hipError_t launch_convert_float (int conv, const uint8_t *iq, uint16_t *mag, siz
 
 hipError_t launch_accept2400 (const AcceptParams &p, hipStream_t stream)
 {
-  if (p.nblocks == 0) return hipSuccess;
-  if (p.mode == 2000) hipLaunchKernelGGL (accept_kernel<2000>, dim3 ((p.nblocks + 3) / 4), dim3 (256), 0, stream, p);
-  else                hipLaunchKernelGGL (accept_kernel<2400>, dim3 ((p.nblocks + 3) / 4), dim3 (256), 0, stream, p);
+  const uint32_t nb = (p.blk_end ? p.blk_end : p.nblocks) - p.blk_begin;
+  if (p.nblocks == 0 || nb == 0) return hipSuccess;
+  if (p.mode == 2000) hipLaunchKernelGGL (accept_kernel<2000>, dim3 (nb), dim3 (64), 0, stream, p);
+  else                hipLaunchKernelGGL (accept_kernel<2400>, dim3 (nb), dim3 (64), 0, stream, p);
   return hipGetLastError ();
 }
 
@@ -1382,7 +1411,7 @@ hipError_t launch_snapshots (const uint32_t *delta, uint32_t nblocks, const uint
 {
   if (nblocks == 0) return hipSuccess;
   const uint32_t nchunks = (nblocks + kSnapChunk - 1) / kSnapChunk;
-  hipLaunchKernelGGL (snap_chunk_last_kernel, dim3 (kIcaoSlots / 256, nchunks), dim3 (256), 0, stream, delta, nblocks, chunk_last);
+  hipLaunchKernelGGL (snap_chunk_last_kernel, dim3 (kIcaoSlots / 256, nchunks), dim3 (256), 0, stream, delta, nblocks, chunk_last, dirty);
   hipLaunchKernelGGL (snap_chunk_scan_kernel, dim3 (kIcaoSlots / 256), dim3 (256), 0, stream, chunk_last, nchunks, cache_in, chunk_entry, cache_out);
   hipLaunchKernelGGL (snap_fill_kernel, dim3 (kIcaoSlots / 256, nchunks), dim3 (256), 0, stream, delta, nblocks, chunk_entry, snap_in, dirty);
   return hipGetLastError ();

@@ -325,8 +325,8 @@ void scan2000_kernel (const ScanParams p)
   WaveLds2000<kTile> &w = lds[wv];
   crc_tab[threadIdx.x & 255] = p.crc_table[threadIdx.x & 255];
   __syncthreads ();
-  const uint32_t strip = blockIdx.x * kWaves2000 + wv;
-  if (strip >= p.nstrips) return;
+  const uint32_t strip = p.strip_begin + blockIdx.x * kWaves2000 + wv;
+  if (strip >= (p.strip_end ? p.strip_end : p.nstrips)) return;
 
   for (int i = lane; i < 256; i += 64) w.lut[i] = p.lut256 ? p.lut256[i] : uint16_t (0);
   if (lane < kWords) { w.ev[0][lane] = 0; w.ev[1][lane] = 0; }
@@ -535,8 +535,9 @@ hipError_t upload_constants_2000 (const uint32_t *single_bit, const float *uc8_f
 
 hipError_t launch_scan2000 (const ScanParams &p, hipStream_t stream)
 {
-  const dim3 grid ((p.nstrips + kWaves2000 - 1) / kWaves2000), block (64 * kWaves2000);
-  if (p.nstrips == 0) return hipSuccess;
+  const uint32_t nlaunch = (p.strip_end ? p.strip_end : p.nstrips) - p.strip_begin;
+  const dim3 grid ((nlaunch + kWaves2000 - 1) / kWaves2000), block (64 * kWaves2000);
+  if (p.nstrips == 0 || nlaunch == 0) return hipSuccess;
 #define SCAN(C)                                                                              \
   do {                                                                                        \
     if (p.phase_enhance) hipLaunchKernelGGL ((scan2000_kernel<C, true>), grid, block, 0, stream, p);   \

@@ -1,16 +1,20 @@
-"""Kernel timeline of the last pipeline step from a rocprofv3 --kernel-trace csv.  Usage: timeline.py dir [first-kernel-substring]"""
+"""Prints one step's timeline from a rocprofv3 --kernel-trace --memory-copy-trace run: every kernel / copy with its
+start relative to the step's first scan kernel, duration and stream, so gaps between dependent launches show."""
 import csv, glob, sys
-f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
-key = sys.argv[2] if len(sys.argv) > 2 else 'scan2400'
-rows = list(csv.DictReader(open(f)))
-rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if key in r['Kernel_Name']]
-i0 = idx[-1]
-t0 = int(rows[i0]['Start_Timestamp'])
-prev_end = t0
-for r in rows[i0:i0 + 48]:
-    s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
-    if (s - prev_end) > 5e6: break
-    name = r['Kernel_Name'].split('(')[0][-44:]
-    print("%9.1f us  gap %7.1f  dur %8.1f  %s" % ((s - t0) / 1e3, (s - prev_end) / 1e3, (e - s) / 1e3, name))
-    prev_end = e
+d = sys.argv[1]
+rows = []
+for f in glob.glob(d + "/**/*_kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:60], r.get("Stream_Id", r.get("Queue_Id", "?"))))
+for f in glob.glob(d + "/**/*_memory_copy_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r.get("Direction", "") , r.get("Stream_Id", "?")))
+rows.sort()
+scans = [i for i, r in enumerate(rows) if r[2].startswith("void modes::scan2") or "scan2400_kernel" in r[2] or "scan2000_kernel" in r[2]]
+nr = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+step = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+i0 = scans[step * nr]
+i1 = scans[(step + 1) * nr] if (step + 1) * nr < len(scans) else len(rows)
+t0 = rows[i0][0]
+for s, e, n, q in rows[i0:i1]:
+    print("%9.1f %8.1f  q%-3s %s" % ((s - t0) / 1e3, (e - s) / 1e3, q, n))
