@@ -182,6 +182,14 @@ struct modes_engine {
   PinBuf<Record> pin_recs;
   PinBuf<uint32_t> pin_bits;                  // announce bitmap as the run starts with it
   PinBuf<uint32_t> pin_counts;                // per-chunk window / record counts
+  PinBuf<uint64_t> pin_rpos;                  // 8 MS/s: positions and lengths of the messages to measure, staged for the device
+  PinBuf<uint32_t> pin_rlen;
+  PinBuf<uint64_t> pin_sums, pin_tot;         // pin_tot: four totals per range of chunks, written by the device
+  DevBuf<uint64_t> d8_tot;
+  PinBuf<D8Window> pin_wins2;                 // a range that outgrew its share of pin_wins / pin_recs
+  PinBuf<Record> pin_recs2;
+  uint64_t d8_last_chunks = 0, d8_last_nwin = 0, d8_last_nrec = 0, d8_last_msgs = 0;   // the last run: sizes the next run's arrays                  // 8 MS/s: signal sums of the accepted messages, range by range
+  std::vector<hipEvent_t> d8_gathered;        // one per range of chunks: its packed windows / records are in pinned memory
   std::vector<hipEvent_t> d8_events;          // three per range of chunks: windows begin / end, counts (then records) on the host
   unsigned long long *d_stats = nullptr;
   uint32_t cap = 0;
@@ -819,7 +827,7 @@ void modes_engine_destroy (modes_engine *e)
   e->d8_trig.release (); e->d8_amb.release (); e->d8_off.release (); e->d8_p0.release (); e->d8_mx.release ();
   e->d8_win_count.release (); e->d8_chunk_rec.release (); e->d8_announce.release (); e->d8_table.release (); e->d8_entry.release ();
   e->d8_win_start.release (); e->d8_small.release (); e->d8_windows.release (); e->d8_win_packed.release ();
-  e->d8_records.release (); e->d8_rec_packed.release (); e->dirty.release (); e->rb.release (); e->pin_rb.release ();
+  e->d8_records.release (); e->d8_rec_packed.release (); e->dirty.release (); e->rb.release (); e->pin_rb.release (); e->pin_sums.release (); e->pin_tot.release (); e->d8_tot.release (); e->pin_wins2.release (); e->pin_recs2.release (); e->pin_rpos.release (); e->pin_rlen.release ();
   e->d8_dprev.release (); e->d8_dnext.release (); e->pin_d8.release ();
   e->d_fields.release (); e->pin_fields.release ();
   if (e->post_stream) (void) hipStreamDestroy (e->post_stream);
@@ -828,6 +836,7 @@ void modes_engine_destroy (modes_engine *e)
   for (hipEvent_t ev : e->range_events) if (ev) (void) hipEventDestroy (ev);
   e->pin_wins.release (); e->pin_recs.release (); e->pin_bits.release (); e->pin_counts.release ();
   for (hipEvent_t ev : e->d8_events) if (ev) (void) hipEventDestroy (ev);
+  for (hipEvent_t ev : e->d8_gathered) if (ev) (void) hipEventDestroy (ev);
   if (e->tabs.short_tab) (void) hipFree (e->tabs.short_tab);
   if (e->tabs.long_tab) (void) hipFree (e->tabs.long_tab);
   if (e->tabs.lut256) (void) hipFree (e->tabs.lut256);
@@ -1223,80 +1232,157 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
     HIP_TRY (hipMemcpyAsync (e->pin_d8.p + kD8Overlap + 6, q.amb_count, sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
   }
   e->d8_q = q; e->d8_limit = limit; e->d8_trig_tail_in = trig_tail_in;
-  // The completed windows in up to four ranges of chunks.  While the host walks one range's records in order (the
-  // part of demod_8000 that needs the live ICAO cache), the device works on the next range: the queue is
-  //   windows(0) count(0) | gather(0) copy(0) windows(1) count(1) | gather(1) copy(1) windows(2) ...
-  // A record of range r can only be accepted through an address announced in ranges <= r (or cached at the start), and
-  // count(r) runs behind windows(r), so the address filter sees all it needs.
-  const uint32_t nranges = nchunks >= 16 ? 4u : 1u;
+  // The completed windows in ranges of chunks.  Everything the device does for a range is queued up front on the
+  // caller's stream, all ranges back to back: windows, count (address filter), offsets (one wave: where each chunk's
+  // live windows and records go), gather -- which writes the packed windows and records straight into pinned host
+  // memory -- and an event.  The host waits for a range's event, walks its records in order (the part of demod_8000
+  // that needs the live ICAO cache) while the device is busy with the ranges behind it, and queues the signal levels of
+  // the messages it accepted on a second stream.  A record of range r can only be accepted through an address announced
+  // in ranges <= r (or cached at the start), and count(r) runs behind windows(r), so the address filter sees all it needs.
+  // The pinned arrays are sized from the last run (or a default per chunk); a range that does not fit is gathered again
+  // into arrays of the right size.  Ranges shrink a little towards the end: what is left when the last window kernel
+  // ends is the walk over the last range.
+  uint32_t nranges = nchunks >= 256 ? 6u : nchunks >= 16 ? 4u : 1u;
+  if (const char *ev = getenv ("MODES_RANGES")) { const int v = atoi (ev); if (v >= 1 && v <= 64) nranges = uint32_t (v) < nchunks ? uint32_t (v) : nchunks; }
   if (e->d8_events.size () < 3 * size_t (nranges)) {
     const size_t have = e->d8_events.size ();
     e->d8_events.resize (3 * size_t (nranges), nullptr);
     for (size_t i = have; i < e->d8_events.size (); i++) HIP_TRY (hipEventCreate (&e->d8_events[i]));
   }
-  if ((rc = e->pin_counts.reserve (3 * size_t (nchunks))) != MODES_OK) return rc;
-  uint32_t *wc = e->pin_counts.p, *rcnt = e->pin_counts.p + nchunks;           // rcnt: [records per chunk | live windows per chunk]
-  auto range_lo = [&] (uint32_t r) { return uint32_t (uint64_t (nchunks) * r / nranges); };
-  auto queue_windows = [&] (uint32_t r) -> int {
-    const uint32_t c0 = range_lo (r), n = range_lo (r + 1) - c0;
+  while (e->d8_gathered.size () < nranges) {
+    hipEvent_t ev;
+    HIP_TRY (hipEventCreateWithFlags (&ev, hipEventDisableTiming));
+    e->d8_gathered.push_back (ev);
+  }
+  if (!e->post_stream) HIP_TRY (hipStreamCreateWithFlags (&e->post_stream, hipStreamNonBlocking));
+  if (!e->copy_stream) HIP_TRY (hipStreamCreateWithFlags (&e->copy_stream, hipStreamNonBlocking));
+  hipStream_t side = e->post_stream, lvl = e->copy_stream;       // gathers (queued up front) / signal levels (queued range by range)
+  struct Drain { hipStream_t a, b, c; ~Drain () { (void) hipStreamSynchronize (a); (void) hipStreamSynchronize (b); (void) hipStreamSynchronize (c); } } drain = { side, lvl, stream };
+  std::vector<uint32_t> lo (nranges + 1);
+  {
+    // each range 0.8 of the one before: the walk over range r (3/4 of the device's time per chunk) ends before the
+    // device is through with range r + 1
+    const double ratio = 0.8;
+    double wsum = 0, run = 0, w = 1.0;
+    for (uint32_t r = 0; r < nranges; r++, w *= ratio) wsum += w;
+    w = 1.0;
+    for (uint32_t r = 0; r < nranges; r++, w *= ratio) { lo[r] = uint32_t (double (nchunks) * run / wsum); run += w; }
+    lo[nranges] = nchunks;
+  }
+  // per-chunk budget of the pinned arrays
+  uint64_t bw = 192, br = 256;
+  if (e->d8_last_chunks) {
+    bw = e->d8_last_nwin * 3 / 2 / e->d8_last_chunks + 32;
+    br = e->d8_last_nrec * 3 / 2 / e->d8_last_chunks + 32;
+  }
+  if (const char *ev = getenv ("MODES_D8_BUDGET")) if (atoi (ev) > 0) bw = br = uint64_t (atoi (ev));      // test hook
+  if ((rc = e->pin_wins.reserve (size_t (nchunks) * bw)) != MODES_OK) return rc;
+  if ((rc = e->pin_recs.reserve (size_t (nchunks) * br + 1)) != MODES_OK) return rc;
+  if ((rc = e->d8_tot.reserve (4 * size_t (nranges))) != MODES_OK) return rc;
+  if ((rc = e->pin_tot.reserve (4 * size_t (nranges))) != MODES_OK) return rc;
+  for (uint32_t r = 0; r < nranges; r++) {
+    const uint32_t c0 = lo[r], n = lo[r + 1] - c0;
     q.chunk0 = c0;
     HIP_TRY (hipEventRecord (e->d8_events[3 * r], stream));
     HIP_TRY (launch_d8_windows (q, n, stream));
     HIP_TRY (hipEventRecord (e->d8_events[3 * r + 1], stream));
     HIP_TRY (launch_d8_count (q, n, e->d8_chunk_rec.p, stream));
-    HIP_TRY (hipMemcpyAsync (wc + c0, e->d8_win_count.p + c0, n * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY (hipMemcpyAsync (rcnt + c0, e->d8_chunk_rec.p + c0, n * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY (hipMemcpyAsync (rcnt + nchunks + c0, e->d8_chunk_rec.p + nchunks + c0, n * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY (launch_d8_offsets (e->d8_chunk_rec.p, e->d8_win_count.p, nchunks, c0, n, e->d8_off.p, e->d8_off.p + nchunks + 1,
+                                uint64_t (n) * bw, uint64_t (n) * br, e->d8_tot.p + 4 * r, e->pin_tot.p + 4 * r, stream));
+    // the gather only reads what count and offsets left: it runs beside the next range's window kernel
     HIP_TRY (hipEventRecord (e->d8_events[3 * r + 2], stream));
-    return MODES_OK;
-  };
+    HIP_TRY (hipStreamWaitEvent (side, e->d8_events[3 * r + 2], 0));
+    HIP_TRY (launch_d8_gather (q, n, e->d8_off.p, e->d8_off.p + nchunks + 1, e->pin_wins.p + size_t (c0) * bw, e->pin_recs.p + size_t (c0) * br,
+                               side, e->d8_tot.p + 4 * r));
+    HIP_TRY (hipEventRecord (e->d8_gathered[r], side));
+  }
   Pass8000Stats ps;
-  std::vector<uint64_t> rpos; std::vector<uint32_t> rlen, rmsg;
-  std::vector<uint64_t> off (2 * size_t (nchunks) + 2);
+  std::vector<uint64_t> rpos; std::vector<uint32_t> rlen;
+  struct LevelOf { size_t msg, sum; uint32_t len; };
+  std::vector<LevelOf> level_of;                        // message, index of its sum in pin_sums, samples summed
+  size_t nsums = 0;
+  uint64_t all_win = 0, all_rec = 0;
   double host_ms = 0.0;
   e->kernel_ms[0] = 0;
-  if ((rc = queue_windows (0)) != MODES_OK) return rc;
+  e->messages.reserve (e->d8_last_msgs + e->d8_last_msgs / 8 + 64);
   for (uint32_t r = 0; r < nranges; r++) {
-    const uint32_t c0 = range_lo (r), c1 = range_lo (r + 1);
-    HIP_TRY (hipEventSynchronize (e->d8_events[3 * r + 2]));
+    const uint32_t c0 = lo[r], c1 = lo[r + 1];
+    HIP_TRY (hipEventSynchronize (e->d8_gathered[r]));
     if (r == 0) (void) hipEventElapsedTime (&e->kernel_ms[1], e->ev[2], e->ev[3]);
-    uint64_t nwin = 0, nrec = 0;
-    for (uint32_t c = c0; c < c1; c++) {
-      if (wc[c] > uint32_t (kD8WinCap)) return fail (MODES_E_OVERFLOW, "chunk %u holds %u windows (cap %d)", c, wc[c], kD8WinCap);
-      off[c] = nwin; off[nchunks + 1 + c] = nrec;
-      nwin += rcnt[nchunks + c]; nrec += rcnt[c];                  // windows and records that survive the address filter
-    }
-    e->stats.candidates += nrec;
-    if (nwin) {
-      if ((rc = e->d8_win_packed.reserve (nwin)) != MODES_OK) return rc;
-      if ((rc = e->d8_rec_packed.reserve (nrec + 1)) != MODES_OK) return rc;
-      if ((rc = e->pin_wins.reserve (nwin)) != MODES_OK) return rc;
-      if ((rc = e->pin_recs.reserve (nrec + 1)) != MODES_OK) return rc;
-      HIP_TRY (hipMemcpyAsync (e->d8_off.p + c0, off.data () + c0, (c1 - c0) * sizeof (uint64_t), hipMemcpyHostToDevice, stream));
-      HIP_TRY (hipMemcpyAsync (e->d8_off.p + nchunks + 1 + c0, off.data () + nchunks + 1 + c0, (c1 - c0) * sizeof (uint64_t), hipMemcpyHostToDevice, stream));
-      q.chunk0 = c0;
-      HIP_TRY (launch_d8_gather (q, c1 - c0, e->d8_off.p, e->d8_off.p + nchunks + 1, e->d8_win_packed.p, e->d8_rec_packed.p, stream));
-      HIP_TRY (hipMemcpyAsync (e->pin_wins.p, e->d8_win_packed.p, nwin * sizeof (D8Window), hipMemcpyDeviceToHost, stream));
-      if (nrec) HIP_TRY (hipMemcpyAsync (e->pin_recs.p, e->d8_rec_packed.p, nrec * sizeof (Record), hipMemcpyDeviceToHost, stream));
-      HIP_TRY (hipEventRecord (e->d8_events[3 * r + 2], stream));
-    }
-    if (r + 1 < nranges && (rc = queue_windows (r + 1)) != MODES_OK) return rc;     // the device's work while the host walks range r
     float wms = 0;
     (void) hipEventElapsedTime (&wms, e->d8_events[3 * r], e->d8_events[3 * r + 1]);
     e->kernel_ms[0] += wms;
+    const uint64_t *tot = e->pin_tot.p + 4 * r;
+    const uint64_t nwin = tot[0], nrec = tot[1];
+    if (tot[2] > uint64_t (kD8WinCap)) return fail (MODES_E_OVERFLOW, "a chunk of range %u holds %llu windows (cap %d)", r, (unsigned long long) tot[2], kD8WinCap);
+    e->stats.candidates += nrec;
+    all_win += nwin; all_rec += nrec;
     if (!nwin) continue;
-    HIP_TRY (hipEventSynchronize (e->d8_events[3 * r + 2]));
+    const D8Window *wins = e->pin_wins.p + size_t (c0) * bw;
+    const Record *recs = e->pin_recs.p + size_t (c0) * br;
+    if (tot[3]) {
+      // the range outgrew its share of the pinned arrays: gather it again (the offsets are right) into arrays of its size
+      e->stats.scan_retries++;
+      if ((rc = e->d8_win_packed.reserve (nwin)) != MODES_OK) return rc;
+      if ((rc = e->d8_rec_packed.reserve (nrec + 1)) != MODES_OK) return rc;
+      if ((rc = e->pin_wins2.reserve (nwin)) != MODES_OK) return rc;
+      if ((rc = e->pin_recs2.reserve (nrec + 1)) != MODES_OK) return rc;
+      q.chunk0 = c0;
+      HIP_TRY (launch_d8_gather (q, c1 - c0, e->d8_off.p, e->d8_off.p + nchunks + 1, e->d8_win_packed.p, e->d8_rec_packed.p, side));
+      HIP_TRY (hipMemcpyAsync (e->pin_wins2.p, e->d8_win_packed.p, nwin * sizeof (D8Window), hipMemcpyDeviceToHost, side));
+      if (nrec) HIP_TRY (hipMemcpyAsync (e->pin_recs2.p, e->d8_rec_packed.p, nrec * sizeof (Record), hipMemcpyDeviceToHost, side));
+      HIP_TRY (hipStreamSynchronize (side));
+      wins = e->pin_wins2.p; recs = e->pin_recs2.p;
+    }
     const auto t_host0 = std::chrono::steady_clock::now ();
-    accept_pass_8000_with (e->pin_wins.p, nwin, e->pin_recs.p, B, q.bshift, T, e->ov, first_sample, e->cfg.sample_rate,
+    rpos.clear (); rlen.clear ();
+    accept_pass_8000_with (wins, nwin, recs, B, q.bshift, T, e->ov, first_sample, e->cfg.sample_rate,
       [&] (const Record &rr, int) { return score_record (rr, e->cache); },
       [&] (const Record &rr, uint64_t, modes_message *out) { return accept_record (rr, e->cache, out); },
       [&] (modes_message &m, const Record &, uint64_t blkc, int m_start, int slen) {
         if (!m.addr) return;                                        // ref: src/demod-8000.c:487
-        if (m_start >= 0) { rpos.push_back (blkc * B + uint64_t (m_start)); rlen.push_back (uint32_t (slen)); rmsg.push_back (uint32_t (e->messages.size ())); }
+        if (m_start >= 0) {
+          rpos.push_back (blkc * B + uint64_t (m_start) - 19);      // the shared kernel sums from position + 19
+          rlen.push_back (uint32_t (slen));
+          level_of.push_back (LevelOf { e->messages.size (), nsums + rpos.size () - 1, uint32_t (slen) });
+        }
         e->messages.push_back (m);
       }, ps);
     host_ms += std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - t_host0).count ();
+    // signal level of the range's messages (ref: :469-484): queued behind the walk, read when all ranges are done
+    const size_t nr = rpos.size ();
+    if (nr) {
+      if (nr > e->rssi_pos.cap || nr > e->rssi_len.cap || nr > e->rssi_sum.cap || nsums + nr > e->pin_sums.cap ||
+          nr > e->pin_rpos.cap || nr > e->pin_rlen.cap)
+        HIP_TRY (hipStreamSynchronize (lvl));                     // nothing of an earlier range is left in what grows
+      if ((rc = e->rssi_pos.reserve (nr)) != MODES_OK) return rc;
+      if ((rc = e->rssi_len.reserve (nr)) != MODES_OK) return rc;
+      if ((rc = e->rssi_sum.reserve (nr)) != MODES_OK) return rc;
+      if (nsums + nr > e->pin_sums.cap) {
+        PinBuf<uint64_t> bigger;
+        if ((rc = bigger.reserve (2 * (nsums + nr))) != MODES_OK) return rc;
+        if (nsums) memcpy (bigger.p, e->pin_sums.p, nsums * sizeof (uint64_t));
+        e->pin_sums.release ();
+        e->pin_sums = bigger;
+      }
+      if ((rc = e->pin_rpos.reserve (nr)) != MODES_OK) return rc;
+      if ((rc = e->pin_rlen.reserve (nr)) != MODES_OK) return rc;
+      HIP_TRY (hipStreamSynchronize (lvl));                       // (idle by now) the staging buffers are reused range by range
+      memcpy (e->pin_rpos.p, rpos.data (), nr * sizeof (uint64_t));
+      memcpy (e->pin_rlen.p, rlen.data (), nr * sizeof (uint32_t));
+      HIP_TRY (hipMemcpyAsync (e->rssi_pos.p, e->pin_rpos.p, nr * sizeof (uint64_t), hipMemcpyHostToDevice, lvl));
+      HIP_TRY (hipMemcpyAsync (e->rssi_len.p, e->pin_rlen.p, nr * sizeof (uint32_t), hipMemcpyHostToDevice, lvl));
+      HIP_TRY (launch_rssi2400 (sp.conv, sp.iq, sp.conv == kConvMagU16 ? sp.navail : sp.nsamples, sp.halo, sp.ov, sp.block_samples,
+                                sp.lut256, e->rssi_pos.p, e->rssi_len.p, e->rssi_sum.p, uint32_t (nr), lvl));
+      HIP_TRY (hipMemcpyAsync (e->pin_sums.p + nsums, e->rssi_sum.p, nr * sizeof (uint64_t), hipMemcpyDeviceToHost, lvl));
+      nsums += nr;
+    }
   }
+  HIP_TRY (hipStreamSynchronize (lvl));
+  HIP_TRY (hipStreamSynchronize (stream));
+  e->d8_last_chunks = nchunks; e->d8_last_nwin = all_win; e->d8_last_nrec = all_rec; e->d8_last_msgs = e->messages.size ();
+  for (const LevelOf &lv : level_of)
+    e->messages[lv.msg].sig_level = (double (e->pin_sums.p[lv.sum]) / 65535.0 / 65535.0) / double (lv.len);
   {
     // the hand-over state (the copies were queued in front of the first range: long done)
     modes_d8_state &o = e->d8_out;
@@ -1325,22 +1411,6 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   e->stats.CRC_good = ps.CRC_good; e->stats.CRC_bad = ps.CRC_bad; e->stats.CRC_single_bit_fix = ps.CRC_single_bit_fix;
   e->stats.CRC_two_bits_fix = ps.CRC_two_bits_fix; e->stats.CRC_fixed = ps.CRC_single_bit_fix + ps.CRC_two_bits_fix;
   e->stats.demod_rejected_unknown = ps.rejected_unknown;
-  const size_t nr = rpos.size ();
-  if (nr) {                                                       // signal level (ref: :469-484)
-    std::vector<uint64_t> sums (nr);
-    for (size_t i = 0; i < nr; i++) rpos[i] -= 19;                // the shared kernel sums from position + 19
-    if ((rc = e->rssi_pos.reserve (nr)) != MODES_OK) return rc;
-    if ((rc = e->rssi_len.reserve (nr)) != MODES_OK) return rc;
-    if ((rc = e->rssi_sum.reserve (nr)) != MODES_OK) return rc;
-    HIP_TRY (hipMemcpyAsync (e->rssi_pos.p, rpos.data (), nr * sizeof (uint64_t), hipMemcpyHostToDevice, stream));
-    HIP_TRY (hipMemcpyAsync (e->rssi_len.p, rlen.data (), nr * sizeof (uint32_t), hipMemcpyHostToDevice, stream));
-    HIP_TRY (launch_rssi2400 (sp.conv, sp.iq, sp.conv == kConvMagU16 ? sp.navail : sp.nsamples, sp.halo, sp.ov, sp.block_samples,
-                              sp.lut256, e->rssi_pos.p, e->rssi_len.p, e->rssi_sum.p, uint32_t (nr), stream));
-    HIP_TRY (hipMemcpyAsync (sums.data (), e->rssi_sum.p, nr * sizeof (uint64_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY (hipStreamSynchronize (stream));
-    for (size_t i = 0; i < nr; i++)
-      e->messages[rmsg[i]].sig_level = (double (sums[i]) / 65535.0 / 65535.0) / double (rlen[i]);
-  }
   return MODES_OK;
 }
 

@@ -29,7 +29,10 @@ hipError_t launch_d8_tail (const D8Params &q, int32_t *dnext, hipStream_t stream
 hipError_t launch_d8_seed (uint32_t *announce, const uint32_t *addr, uint32_t n, hipStream_t stream);
 hipError_t launch_d8_count (const D8Params &q, uint32_t nch, uint32_t *chunk_rec, hipStream_t stream);
 hipError_t launch_d8_gather (const D8Params &q, uint32_t nch, const uint64_t *win_off, const uint64_t *rec_off, D8Window *win_out,
-                             Record *rec_out, hipStream_t stream);
+                             Record *rec_out, hipStream_t stream, const uint64_t *range_tot = nullptr);
+hipError_t launch_d8_offsets (const uint32_t *chunk_rec, const uint32_t *win_count, uint32_t nchunks, uint32_t c0, uint32_t n,
+                              uint64_t *win_off, uint64_t *rec_off, uint64_t cap_w, uint64_t cap_r, uint64_t *tot, uint64_t *tot_host,
+                              hipStream_t stream);
 hipError_t launch_convert (int conv, const uint8_t *iq, uint16_t *mag, size_t n, const uint16_t *lut256,
                            unsigned long long *power_u64, hipStream_t stream);
 hipError_t launch_rssi2400 (int conv, const uint8_t *iq, uint64_t nsamples, const uint16_t *halo, uint32_t ov,

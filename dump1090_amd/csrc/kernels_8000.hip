@@ -600,10 +600,52 @@ void d8_count_kernel (const D8Params q, uint32_t *chunk_rec)
   if (threadIdx.x == 0) chunk_rec[q.nchunks + c] = part[0];
 }
 
+// Where each chunk of a range of chunks puts its live windows and records in the range's packed arrays (one wave).
+// tot[0..3] = live windows, records, largest window count of a chunk, 1 if the range does not fit `cap_w` windows /
+// `cap_r` records (or a chunk overflowed its window slots): the gather then leaves the arrays alone.  tot_host gets a
+// copy (pinned host memory the host reads once the range's event has fired).
+__global__ __launch_bounds__ (64)
+void d8_offsets_kernel (const uint32_t *chunk_rec, const uint32_t *win_count, uint32_t nchunks, uint32_t c0, uint32_t n,
+                        uint64_t *win_off, uint64_t *rec_off, uint64_t cap_w, uint64_t cap_r, uint64_t *tot, uint64_t *tot_host)
+{
+  const int lane = threadIdx.x;
+  uint64_t wrun = 0, rrun = 0;
+  uint32_t mx = 0;
+  for (uint32_t base = 0; base < n; base += 64) {
+    const uint32_t c = c0 + base + lane;
+    const bool have = base + lane < n;
+    const uint64_t r = have ? chunk_rec[c] : 0, w = have ? chunk_rec[nchunks + c] : 0;
+    if (have) mx = max (mx, win_count[c]);
+    uint64_t ri = r, wi = w;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint64_t ro = __shfl_up (ri, d, 64), wo = __shfl_up (wi, d, 64);
+      if (lane >= d) { ri += ro; wi += wo; }
+    }
+    if (have) { rec_off[c] = rrun + ri - r; win_off[c] = wrun + wi - w; }
+    rrun += __shfl (ri, 63, 64); wrun += __shfl (wi, 63, 64);
+  }
+  for (int d = 32; d >= 1; d >>= 1) mx = max (mx, uint32_t (__shfl_xor (int (mx), d, 64)));
+  if (lane == 0) {
+    const uint64_t over = (wrun > cap_w || rrun > cap_r || mx > uint32_t (kD8WinCap)) ? 1 : 0;
+    tot[0] = wrun; tot[1] = rrun; tot[2] = mx; tot[3] = over;
+    tot_host[0] = wrun; tot_host[1] = rrun; tot_host[2] = mx; tot_host[3] = over;
+  }
+}
+
+hipError_t launch_d8_offsets (const uint32_t *chunk_rec, const uint32_t *win_count, uint32_t nchunks, uint32_t c0, uint32_t n,
+                              uint64_t *win_off, uint64_t *rec_off, uint64_t cap_w, uint64_t cap_r, uint64_t *tot, uint64_t *tot_host,
+                              hipStream_t stream)
+{
+  hipLaunchKernelGGL (d8_offsets_kernel, dim3 (1), dim3 (64), 0, stream, chunk_rec, win_count, nchunks, c0, n, win_off, rec_off, cap_w, cap_r, tot, tot_host);
+  return hipGetLastError ();
+}
+
 __global__ __launch_bounds__ (256)
-void d8_gather_kernel (const D8Params q, const uint64_t *win_off, const uint64_t *rec_off, D8Window *win_out, Record *rec_out)
+void d8_gather_kernel (const D8Params q, const uint64_t *win_off, const uint64_t *rec_off, D8Window *win_out, Record *rec_out,
+                       const uint64_t *range_tot)
 {
   __shared__ uint32_t pre[kD8WinCap + 1], wpre[kD8WinCap + 1];
+  if (range_tot && range_tot[3]) return;                        // the range does not fit where it should go
   const uint32_t c = q.chunk0 + blockIdx.x, nwin = min (q.win_count[c], uint32_t (kD8WinCap));
   if (threadIdx.x == 0) {
     uint32_t run = 0, wrun = 0;
@@ -639,9 +681,9 @@ hipError_t launch_d8_count (const D8Params &q, uint32_t nch, uint32_t *chunk_rec
 }
 
 hipError_t launch_d8_gather (const D8Params &q, uint32_t nch, const uint64_t *win_off, const uint64_t *rec_off, D8Window *win_out,
-                             Record *rec_out, hipStream_t stream)
+                             Record *rec_out, hipStream_t stream, const uint64_t *range_tot)
 {
-  if (nch) hipLaunchKernelGGL (d8_gather_kernel, dim3 (nch), dim3 (256), 0, stream, q, win_off, rec_off, win_out, rec_out);
+  if (nch) hipLaunchKernelGGL (d8_gather_kernel, dim3 (nch), dim3 (256), 0, stream, q, win_off, rec_off, win_out, rec_out, range_tot);
   return hipGetLastError ();
 }
 

@@ -89,3 +89,28 @@ def test_long_recording_runs_in_chunk_ranges():
     assert_same_messages(got, exp)
     for k in STAT_KEYS:
         assert gst[k] == est[k], (k, gst[k], est[k])
+
+
+def test_range_that_outgrows_its_pinned_share_is_gathered_again():
+    """The packed windows / records of a range go straight to pinned host arrays sized from the last run (or a default
+    per chunk); a range that does not fit is gathered again into arrays of its own size (MODES_D8_BUDGET: test hook)."""
+    import os
+    iq, _ = synth.capture(17 * 65536 * 8 // 2 + 999, 8.0e6, "sc16", seed=92, frames_per_sec=2500, n_icao=8)
+    iq = np.concatenate([iq, iq])                                 # 17+ chunks: four ranges
+    exp, est = oracle_run(iq, "sc16", rate=8000000)
+    assert len(exp) > 1000
+    os.environ["MODES_D8_BUDGET"] = "1"
+    try:
+        e = da.Engine(8000000, da.INPUT_SC16)
+        e.run_host(iq)
+    finally:
+        del os.environ["MODES_D8_BUDGET"]
+    assert e.stats()["scan_retries"] >= 1
+    assert_same_messages(e.messages(), exp)
+    for k in STAT_KEYS:
+        assert e.stats()[k] == est[k], k
+    # a second run on the same engine sizes the arrays from the first: nothing is gathered twice
+    e.set_icao(np.zeros(1024, dtype=np.uint32))
+    e.run_host(iq)
+    assert e.stats()["scan_retries"] == 0
+    assert_same_messages(e.messages(), exp)
