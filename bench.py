@@ -240,7 +240,7 @@ def run_workload(name, args, world, rank, local, dev, want_cpu):
                               "the gather of the lists to rank 0 is measured here, outside it"}
 
     # dominant kernel: HIP events on the launch stream around it, averaged over the timed steps
-    kernel_ms = kms / args.steps / nrec                           # per launch
+    kernel_ms = kms / args.steps / nrec                           # per recording (a long shard's scan is up to four launches: their sum)
     # algorithmic bytes per sample: the IQ bytes the selected converter has to read
     alg_bps = 1 if (fmt == "uc8" and not power) else bps
     achieved = nsamples * alg_bps / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
@@ -248,9 +248,9 @@ def run_workload(name, args, world, rank, local, dev, want_cpu):
     if traffic is None and args.gib == 4.0 and nrec == 1:
         # HBM bytes per launch of the scan kernel from the committed PMC passes (profiles/README.md), same size and seed
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")) as f:
-                traffic = json.load(f).get(name, {}).get("scan2400_traffic_bytes_per_launch")
-        except OSError:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_hbm.json")) as f:
+                traffic = json.load(f).get(name, {}).get("traffic_bytes_per_step")
+        except (OSError, ValueError):
             traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kernel,
@@ -259,14 +259,24 @@ def run_workload(name, args, world, rank, local, dev, want_cpu):
         # what binds the scan kernel is VALU issue, not HBM: instruction counts per strip from the committed
         # PMC pass (profiles/README.md) priced at 4 cycles per wave64 instruction and 1024 SIMDs at 2.4 GHz
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_scan_stages.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_scan_stages.json")) as f:
                 pm = json.load(f)[fmt]["per_strip"]["through_stage_D"]
             floor_ms = pm["INSTS_VALU"] * 4 * (nsamples / 2048 / 1024) / 2.4e9 * 1e3
             roofline["valu_issue"] = {"insts_per_2048_positions": pm["INSTS_VALU"], "floor_ms": round(floor_ms, 4),
                                       "frac_of_kernel_ms": round(floor_ms / kernel_ms, 3) if kernel_ms > 0 else None,
-                                      "source": "profiles/r01_pmc_scan_stages.json"}
+                                      "source": "profiles/r02_pmc_scan_stages.json"}
         except (OSError, KeyError):
             pass
+    if kernel in ("scan2400_kernel", "scan2000_kernel") and not dc and nrec == 1 and not sharded:
+        # A message-heavy shard is scanned in ranges of blocks whose launches share the GPU with the ordered pass and the
+        # read-back of the range before (kernel_ms above: their sum, as timed inside the step).  The same kernel alone,
+        # one launch over the whole shard, outside the timed region:
+        try:
+            alone = eng.time_scan(recs[0][0].data_ptr(), nbytes, reps=3, stream=stream)
+            roofline["kernel_ms_alone"] = round(alone, 4)
+            roofline["achieved_alone"] = round(nsamples * alg_bps / (alone * 1e-3) / 1e9, 1)
+        except Exception as ex:                    # a report, never a reason to lose the bench line
+            roofline["kernel_ms_alone"] = repr(ex)
     if k2:
         roofline["second_kernel"] = {"kernel": "scan2400_kernel" if dc else "d8_trig_kernel", "kernel_ms": round(k2 / args.steps / nrec, 4)}
     if dc:
@@ -346,7 +356,7 @@ def run_workload(name, args, world, rank, local, dev, want_cpu):
                                + (", ONE %.0f GiB recording sharded over %d GPUs" % (world * nbytes / (1 << 30), world) if sharded else ""),
                    "converter": conv_name, "demod": "demod_%d%s" % (rate // 1000, "+demod_2400_AC" if ekw.get("mode_ac") else ""),
                    "fix_bits": ekw.get("fix_bits", 1), "frames_injected_per_gpu": int(sum(len(i["pos"]) for _, i in recs)),
-                   "concurrent_engines": nlanes},
+                   "concurrent_engines": nlanes, "recordings_per_gpu": nrec},
         "msgs": int(nmsg.item()), "msgs_per_s": round(int(nmsg.item()) / step_s, 1),
         "valid_preamble": stats["valid_preamble"], "candidates": stats["candidates"],
         "roofline": roofline, "cpu_baseline": cpu, "gen_seconds": round(gen_s, 1), "shard": shard_info}

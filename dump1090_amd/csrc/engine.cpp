@@ -202,7 +202,7 @@ struct modes_engine {
   DevBuf<float> dc_zc;
   DevBuf<long long> dc_closed;
   DevBuf<unsigned long long> dc_ticks;
-  hipEvent_t dc_ev[2] = { nullptr, nullptr };
+  hipEvent_t dc_ev[4] = { nullptr, nullptr, nullptr, nullptr };   // around the chain launch / around each repair launch
   float dc_A = 0.0f, dc_B = 1.0f, dc_z[2] = { 0.0f, 0.0f };
   uint64_t dc_lead = 0, dc_warm = 0;
   modes_dc_info dc_info;
@@ -431,7 +431,7 @@ int prepare_dc (modes_engine *e, const void *d_iq, size_t nbytes, const uint16_t
     HIP_TRY (hipMemsetAsync (e->dc_ticks.p, 0, 16 * K * sizeof (unsigned long long), stream));
     q.ticks = e->dc_ticks.p;
   }
-  if (!e->dc_ev[0]) { HIP_TRY (hipEventCreate (&e->dc_ev[0])); HIP_TRY (hipEventCreate (&e->dc_ev[1])); }
+  if (!e->dc_ev[0]) for (hipEvent_t &ev : e->dc_ev) HIP_TRY (hipEventCreate (&ev));
   HIP_TRY (hipMemcpyAsync (e->dc_desc.p, desc.data (), K * sizeof (DcChunk), hipMemcpyHostToDevice, stream));
   HIP_TRY (hipEventRecord (e->dc_ev[0], stream));
   HIP_TRY (launch_dc_chain (e->conv, q, uint32_t (K), stream));
@@ -493,9 +493,12 @@ int prepare_dc (modes_engine *e, const void *d_iq, size_t nbytes, const uint16_t
     std::vector<float> fe (2 * fix.size ());
     HIP_TRY (hipMemcpyAsync (e->dc_desc.p + K, fix.data (), fix.size () * sizeof (DcChunk), hipMemcpyHostToDevice, stream));
     q.desc = e->dc_desc.p + K;
+    HIP_TRY (hipEventRecord (e->dc_ev[2], stream));
     HIP_TRY (launch_dc_chain (e->conv, q, uint32_t (fix.size ()), stream));
+    HIP_TRY (hipEventRecord (e->dc_ev[3], stream));
     HIP_TRY (hipMemcpyAsync (fe.data (), e->dc_ze.p + 2 * K, fe.size () * sizeof (float), hipMemcpyDeviceToHost, stream));
     HIP_TRY (hipStreamSynchronize (stream));
+    { float ms = 0; (void) hipEventElapsedTime (&ms, e->dc_ev[2], e->dc_ev[3]); e->dc_info.chain_ms += ms; }    // chain_ms: every launch of the chain kernel
     for (size_t i = 0; i < fix.size (); i++) {
       const uint64_t c = fix_of[i];
       good[c] = fe[2 * i] == zc[2 * c] && fe[2 * i + 1] == zc[2 * c + 1];
@@ -513,9 +516,12 @@ int prepare_dc (modes_engine *e, const void *d_iq, size_t nbytes, const uint16_t
     d.zIlo = d.zIhi = pe[0]; d.zQlo = d.zQhi = pe[1];
     HIP_TRY (hipMemcpyAsync (e->dc_desc.p + 2 * K, &d, sizeof d, hipMemcpyHostToDevice, stream));
     q.desc = e->dc_desc.p + 2 * K;
+    HIP_TRY (hipEventRecord (e->dc_ev[2], stream));
     HIP_TRY (launch_dc_chain (e->conv, q, 1, stream));
+    HIP_TRY (hipEventRecord (e->dc_ev[3], stream));
     HIP_TRY (hipMemcpyAsync (&ze[2 * c], e->dc_ze.p + 2 * (2 * K), 2 * sizeof (float), hipMemcpyDeviceToHost, stream));
     HIP_TRY (hipStreamSynchronize (stream));
+    { float ms = 0; (void) hipEventElapsedTime (&ms, e->dc_ev[2], e->dc_ev[3]); e->dc_info.chain_ms += ms; }
     e->dc_info.rerun_chunks++;
   }
   e->dc_z[0] = ze[2 * (K - 1)]; e->dc_z[1] = ze[2 * (K - 1) + 1];

@@ -1,35 +1,82 @@
-"""gpurun_out/profiles_raw (tools/collect_profiles.sh) -> profiles/r01_*: kernel stats of this library's kernels per
-workload, and the scan kernel's HBM traffic per launch from FETCH_SIZE / WRITE_SIZE (separate passes)."""
-import csv, glob, json, os, collections
-raw, out = "gpurun_out/profiles_raw", "profiles"
+"""gpurun_out/profiles_raw (tools/collect_profiles.sh) -> profiles/r02_*: kernel stats of this library's kernels per
+workload with the bench line of the same run, and the dominant kernel's HBM traffic per step from FETCH_SIZE / WRITE_SIZE
+(separate passes).  Fails when a workload's kernel-stats CSV and its bench line disagree by more than 10 % on the
+dominant kernel's time per step: then they are not from one run (or the live HIP-event timing is off)."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+raw, out, tag = "gpurun_out/profiles_raw", "profiles", "r02"
+RUNS = 4                                                  # bench.py --steps 3 --warmup 1
 os.makedirs(out, exist_ok=True)
-for old in glob.glob(out + "/r01_*"):
-    if "pmc_scan_stages" not in old:                 # written by tools/stage_pmc_json.py
-        os.remove(old)
+bad = []
 for d in sorted(glob.glob(raw + "/stats_*")):
     wl = os.path.basename(d)[6:]
-    f = glob.glob(d + "/*/*kernel_stats.csv")[0]
-    rows = list(csv.reader(open(f)))
+    files = glob.glob(d + "/*/*kernel_stats.csv")
+    if len(files) != 1:
+        sys.exit("%s: expected one kernel_stats.csv, found %d" % (d, len(files)))
+    rows = list(csv.reader(open(files[0])))
     keep = [rows[0]] + [r for r in rows[1:] if "modes::" in r[0]]
-    csv.writer(open("%s/r01_kernel_stats_%s.csv" % (out, wl), "w")).writerows(keep)
     b = json.load(open("%s/bench_%s.json" % (raw, wl)))
-    json.dump(b, open("%s/r01_bench_under_rocprof_%s.json" % (out, wl), "w"), indent=1)
+    kern = b["roofline"]["kernel"]
+    total_ns = sum(float(r[2]) for r in keep[1:] if kern in r[0])
+    alone = b["roofline"].get("kernel_ms_alone")
+    if isinstance(alone, float):                          # bench.py: three more launches of the kernel, alone, behind the timed steps
+        total_ns -= 3 * alone * 1e6
+    per_step_ms = total_ns / RUNS / 1e6 / max(1, b["config"].get("recordings_per_gpu", 1))      # bench.py: kernel_ms is per recording
+    live = b["roofline"]["kernel_ms"]
+    rel = abs(per_step_ms - live) / live if live else 1.0
+    print("%-14s %-18s csv %.4f ms/step  bench %.4f ms  (%.1f %%)" % (wl, kern, per_step_ms, live, 100 * rel))
+    # engines running side by side on their own streams (sc16_2400ac): a launch's events also bracket time it waited
+    # for a CU behind the other streams' kernels, the profiler's duration does not
+    if rel > (0.10 if b["config"].get("concurrent_engines", 1) == 1 else 0.25):
+        bad.append(wl)
+    csv.writer(open("%s/%s_kernel_stats_%s.csv" % (out, tag, wl), "w")).writerows(keep)
+    json.dump(b, open("%s/%s_bench_under_rocprof_%s.json" % (out, tag, wl), "w"), indent=1)
+if bad:
+    sys.exit("kernel stats and bench line differ by more than 10 %% for: %s" % ", ".join(bad))
+
 hbm = {}
-for wl in ("uc8_2400", "sc16_2400"):
+for f in sorted(glob.glob(raw + "/FETCH_SIZE_*.json")):
+    wl = os.path.basename(f)[len("FETCH_SIZE_"):-5]
     res = {}
-    for ctr in ("fetch", "write"):
-        f = glob.glob("%s/%s_%s/*/*counter_collection.csv" % (raw, ctr, wl))[0]
+    try:
+        b = json.loads(open(f).read().strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        continue
+    kern = b["roofline"]["kernel"]
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        files = glob.glob("%s/%s_%s/*/*counter_collection.csv" % (raw, ctr, wl))
+        if len(files) != 1:
+            sys.exit("%s %s: expected one counter_collection.csv, found %d" % (ctr, wl, len(files)))
         acc = collections.defaultdict(list)
-        for r in csv.DictReader(open(f)):
+        for r in csv.DictReader(open(files[0])):
             if "modes::" in r["Kernel_Name"]:
                 acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
-        res[ctr.upper() + "_SIZE_mean_KB"] = {k: round(sum(v) / len(v), 1) for k, v in acc.items()}
-    scan = [k for k in res["FETCH_SIZE_mean_KB"] if "scan2400" in k][0]
-    fetch, write = res["FETCH_SIZE_mean_KB"][scan], res["WRITE_SIZE_mean_KB"][scan]
-    res["scan2400_traffic_bytes_per_launch"] = int((2 * fetch + write) * 1024)
-    res["note"] = ("FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM: gfx950 reports half the bytes of wide coalesced reads); "
-                   "WRITE_SIZE as reported; KB units; separate --pmc passes")
+        res[ctr + "_KB_per_step"] = {k: round(sum(v) / RUNS, 1) for k, v in acc.items()}
+        res[ctr + "_launches_per_step"] = {k: round(len(v) / RUNS, 2) for k, v in acc.items()}
+    # bench.py launches the scan kernel three more times, alone, behind the timed steps (roofline.kernel_ms_alone): each
+    # is one more pass over the shard
+    extra = 3 if isinstance(b["roofline"].get("kernel_ms_alone"), float) else 0
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        for k in res[ctr + "_KB_per_step"]:
+            if kern in k and extra:
+                res[ctr + "_KB_per_step"][k] = round(res[ctr + "_KB_per_step"][k] * RUNS / (RUNS + extra), 1)
+                res[ctr + "_launches_per_step"][k] = round((res[ctr + "_launches_per_step"][k] * RUNS - extra) / RUNS, 2)
+    fetch = sum(v for k, v in res["FETCH_SIZE_KB_per_step"].items() if kern in k)
+    write = sum(v for k, v in res["WRITE_SIZE_KB_per_step"].items() if kern in k)
+    res["kernel"] = kern
+    res["traffic_bytes_per_step"] = int((2 * fetch + write) * 1024)
+    res["all_kernels_traffic_bytes_per_step"] = int((2 * sum(res["FETCH_SIZE_KB_per_step"].values()) + sum(res["WRITE_SIZE_KB_per_step"].values())) * 1024)
     hbm[wl] = res
-json.dump(hbm, open(out + "/r01_pmc_hbm.json", "w"), indent=1)
-for wl, r in hbm.items():
-    print(wl, "scan traffic per launch: %.3f GB" % (r["scan2400_traffic_bytes_per_launch"] / 1e9))
+if hbm:
+    hbm["note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes without tracing options, on bench.py --steps 3 --warmup 1; "
+                   "KB summed over the launches of a kernel and divided by the 4 steps run.  traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: "
+                   "FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM: gfx950 reports half the bytes of wide coalesced reads), WRITE_SIZE as reported.")
+    json.dump(hbm, open("%s/%s_pmc_hbm.json" % (out, tag), "w"), indent=1)
+    for wl, r in hbm.items():
+        if wl != "note":
+            print("%-14s %-18s traffic per step %.3f GB (all kernels %.3f GB)" % (wl, r["kernel"], r["traffic_bytes_per_step"] / 1e9, r["all_kernels_traffic_bytes_per_step"] / 1e9))
