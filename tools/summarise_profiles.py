@@ -24,8 +24,8 @@ for d in sorted(glob.glob(raw + "/stats_*")):
     kern = b["roofline"]["kernel"]
     total_ns = sum(float(r[2]) for r in keep[1:] if kern in r[0])
     alone = b["roofline"].get("kernel_ms_alone")
-    if isinstance(alone, float):                          # bench.py: three more launches of the kernel, alone, behind the timed steps
-        total_ns -= 3 * alone * 1e6
+    if isinstance(alone, float):                          # bench.py: one more launch of the kernel, alone, behind the timed steps
+        total_ns -= alone * 1e6
     per_step_ms = total_ns / RUNS / 1e6 / max(1, b["config"].get("recordings_per_gpu", 1))      # bench.py: kernel_ms is per recording
     live = b["roofline"]["kernel_ms"]
     rel = abs(per_step_ms - live) / live if live else 1.0
@@ -58,14 +58,16 @@ for f in sorted(glob.glob(raw + "/FETCH_SIZE_*.json")):
                 acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
         res[ctr + "_KB_per_step"] = {k: round(sum(v) / RUNS, 1) for k, v in acc.items()}
         res[ctr + "_launches_per_step"] = {k: round(len(v) / RUNS, 2) for k, v in acc.items()}
-    # bench.py launches the scan kernel three more times, alone, behind the timed steps (roofline.kernel_ms_alone): each
-    # is one more pass over the shard
-    extra = 3 if isinstance(b["roofline"].get("kernel_ms_alone"), float) else 0
+    # bench.py decodes the recording once more behind the timed steps, scanned in one launch (roofline.kernel_ms_alone)
+    extra = 1 if isinstance(b["roofline"].get("kernel_ms_alone"), float) else 0
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         for k in res[ctr + "_KB_per_step"]:
-            if kern in k and extra:
+            if extra:                                     # every kernel of the decode ran once more
                 res[ctr + "_KB_per_step"][k] = round(res[ctr + "_KB_per_step"][k] * RUNS / (RUNS + extra), 1)
-                res[ctr + "_launches_per_step"][k] = round((res[ctr + "_launches_per_step"][k] * RUNS - extra) / RUNS, 2)
+                if kern in k:
+                    res[ctr + "_launches_per_step"][k] = round((res[ctr + "_launches_per_step"][k] * RUNS - extra) / RUNS, 2)
+                else:
+                    res[ctr + "_launches_per_step"][k] = round(res[ctr + "_launches_per_step"][k] * RUNS / (RUNS + extra), 2)
     fetch = sum(v for k, v in res["FETCH_SIZE_KB_per_step"].items() if kern in k)
     write = sum(v for k, v in res["WRITE_SIZE_KB_per_step"].items() if kern in k)
     res["kernel"] = kern
