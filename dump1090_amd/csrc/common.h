@@ -55,7 +55,7 @@ constexpr int kD8Ambig = 4576;           // 2*max > 3*av is settled without av a
 constexpr int kD8SaneMax = 50000000;
 constexpr int kD8StripSteps = 256;       // bit steps (8 samples each) per wave of the trigger kernel
 constexpr int kD8ChunkSteps = 65536;     // bit steps per chunk of the window-chain kernels
-constexpr int kD8WinCap = kD8ChunkSteps / kD8Net + 2;
+constexpr int kD8WinCap = kD8ChunkSteps / kD8Net + 6;   // openings are >= kD8Net steps apart (580 in a chunk); the first chunk also lists up to three carried in from the steps before it
 constexpr int kD8Cand = 32;              // candidate messages per window: 16 bit shifts x (short, long)
 
 // Candidate classes (what the ordered accept pass needs to know about a record)
