@@ -142,6 +142,11 @@ struct AcceptParams {
   const uint32_t *dirty;         // [nblocks] 1 = the block's entry cache changed since the round before (null: run every block)
   int32_t         mode;          // 2400 or 2000: which demodulator's loop is replayed
   uint32_t        blk_begin, blk_end;   // the launch covers these blocks of the shard (blk_end 0 = nblocks)
+  // First round of a pass: every block starts from `cache_in` (snap_in holds nothing yet) and nothing of the round
+  // before is compared.  blk_wrote[block] = the block wrote a cache slot (only then its delta row is valid).
+  const uint32_t *cache_in;
+  uint32_t       *blk_wrote;
+  int32_t         first_round;
 };
 
 // One completed match window of demod_8000 (ref: src/demod-8000.c:331-420)

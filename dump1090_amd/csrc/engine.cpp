@@ -165,7 +165,7 @@ struct modes_engine {
   DevBuf<uint32_t> d8_p0, d8_mx, d8_win_count, d8_chunk_rec, d8_announce;
   DevBuf<uint8_t> d8_table, d8_entry;
   DevBuf<int64_t> d8_win_start, d8_small;
-  DevBuf<uint32_t> dirty;
+  DevBuf<uint32_t> dirty, blk_wrote;
   hipStream_t post_stream = nullptr;          // ordered pass and emit of one range of blocks while the next is scanned
   hipStream_t copy_stream = nullptr;          // read-back of a range's messages
   std::vector<hipEvent_t> emit_events;        // one per range: its messages are formed
@@ -571,6 +571,7 @@ int reserve_accept_buffers (modes_engine *e, const ScanParams &sp)
   if ((rc = e->rb.reserve (kRbWords)) != MODES_OK) return rc;
   if ((rc = e->pin_rb.reserve (kRbWords)) != MODES_OK) return rc;
   if ((rc = e->dirty.reserve (nblocks)) != MODES_OK) return rc;
+  if ((rc = e->blk_wrote.reserve (nblocks)) != MODES_OK) return rc;
   if ((rc = e->chunk_sum.reserve (nsc + 1)) != MODES_OK) return rc;
   if ((rc = e->chunk_vp.reserve (nsc + 1)) != MODES_OK) return rc;
   if ((rc = e->chunk_ovf.reserve (nsc + 1)) != MODES_OK) return rc;
@@ -595,10 +596,10 @@ int accept_range (modes_engine *e, const ScanParams &sp, uint64_t first_sample, 
   // totals of the range's scan (candidates, valid preambles, overflowed strips)
   HIP_TRY (launch_count_scan (e->counts.p + rg.strip0, e->vp_counts.p + rg.strip0, rg.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p, d_totals, stream));
   HIP_TRY (hipMemcpyAsync (d_cache_in, e->cache.raw (), kIcaoSlots * sizeof (uint32_t), hipMemcpyHostToDevice, stream));
-  HIP_TRY (hipMemsetAsync (delta, 0, size_t (nblocks) * kIcaoSlots * sizeof (uint32_t), stream));
   HIP_TRY (hipMemsetAsync (acc_counts, 0, size_t (rg.nstrips) * sizeof (uint32_t), stream));
   HIP_TRY (hipMemsetAsync (d_changed, 0, kRbRounds * sizeof (uint32_t), stream));
-  HIP_TRY (launch_snap_broadcast (d_cache_in, nblocks, snap_in, stream));
+  // (no per-block state is prepared: in the first round every block starts from d_cache_in, writes its delta row only
+  // if it wrote a slot, and says so in blk_wrote)
 
   AcceptParams ap;
   memset (&ap, 0, sizeof ap);
@@ -608,6 +609,7 @@ int accept_range (modes_engine *e, const ScanParams &sp, uint64_t first_sample, 
   ap.snap_in = e->snap_in.p; ap.delta = e->delta.p; ap.acc_counts = e->acc_counts.p; ap.blk_stats = e->blk_stats.p;
   ap.vp_bitmap = e->mode == 2400 ? e->vp_bitmap.p : nullptr;
   ap.mode = e->mode;
+  ap.cache_in = d_cache_in; ap.blk_wrote = e->blk_wrote.p; ap.first_round = 1;
 
   // Every round queues what the last round needs behind it (snapshots, totals, the cache behind the range), so the host
   // waits once per round, for one copy, and the round that finds nothing changed is already the complete result.
@@ -617,8 +619,10 @@ int accept_range (modes_engine *e, const ScanParams &sp, uint64_t first_sample, 
     if (rounds && slot == 0) HIP_TRY (hipMemsetAsync (d_changed, 0, kRbRounds * sizeof (uint32_t), stream));
     ap.changed = d_changed + slot;
     HIP_TRY (launch_accept2400 (ap, stream));
-    HIP_TRY (launch_snapshots (delta, nblocks, d_cache_in, e->chunk_last.p, e->chunk_entry.p, snap_in, d_cache_out, dirty, stream));
+    HIP_TRY (launch_snapshots (delta, e->blk_wrote.p + rg.blk0, nblocks, d_cache_in, e->chunk_last.p, e->chunk_entry.p, snap_in, d_cache_out, dirty,
+                               ap.changed, ap.first_round, stream));
     ap.dirty = e->dirty.p;                                      // from the second round on
+    ap.first_round = 0;
     // totals of accepted messages and the block statistics, read back together with the scan's totals
     HIP_TRY (launch_count_scan (acc_counts, e->vp_counts.p + rg.strip0, rg.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p, d_totals + 4, stream));
     HIP_TRY (launch_blk_stats_sum (blk_stats, nblocks, reinterpret_cast<unsigned long long *> (d_totals + 8), stream));
@@ -833,7 +837,7 @@ void modes_engine_destroy (modes_engine *e)
   e->d8_trig.release (); e->d8_amb.release (); e->d8_off.release (); e->d8_p0.release (); e->d8_mx.release ();
   e->d8_win_count.release (); e->d8_chunk_rec.release (); e->d8_announce.release (); e->d8_table.release (); e->d8_entry.release ();
   e->d8_win_start.release (); e->d8_small.release (); e->d8_windows.release (); e->d8_win_packed.release ();
-  e->d8_records.release (); e->d8_rec_packed.release (); e->dirty.release (); e->rb.release (); e->pin_rb.release (); e->pin_sums.release (); e->pin_tot.release (); e->d8_tot.release (); e->pin_wins2.release (); e->pin_recs2.release (); e->pin_rpos.release (); e->pin_rlen.release ();
+  e->d8_records.release (); e->d8_rec_packed.release (); e->dirty.release (); e->blk_wrote.release (); e->rb.release (); e->pin_rb.release (); e->pin_sums.release (); e->pin_tot.release (); e->d8_tot.release (); e->pin_wins2.release (); e->pin_recs2.release (); e->pin_rpos.release (); e->pin_rlen.release ();
   e->d8_dprev.release (); e->d8_dnext.release (); e->pin_d8.release ();
   e->d_fields.release (); e->pin_fields.release ();
   if (e->post_stream) (void) hipStreamDestroy (e->post_stream);

@@ -48,9 +48,9 @@ hipError_t launch_fields (const void *msgs, uint32_t n, struct ::modes_fields *o
 hipError_t launch_dc_chain (int conv, const DcParams &p, uint32_t ndesc, hipStream_t stream);
 hipError_t launch_dc_linear (int conv, const uint8_t *iq, uint64_t n, double A, double B, double *out, hipStream_t stream);
 hipError_t launch_accept2400 (const AcceptParams &p, hipStream_t stream);
-hipError_t launch_snapshots (const uint32_t *delta, uint32_t nblocks, const uint32_t *cache_in, uint32_t *chunk_last,
-                             uint32_t *chunk_entry, uint32_t *snap_in, uint32_t *cache_out, uint32_t *dirty, hipStream_t stream);
-hipError_t launch_snap_broadcast (const uint32_t *cache_in, uint32_t nblocks, uint32_t *snap_in, hipStream_t stream);
+hipError_t launch_snapshots (const uint32_t *delta, const uint32_t *blk_wrote, uint32_t nblocks, const uint32_t *cache_in, uint32_t *chunk_last,
+                             uint32_t *chunk_entry, uint32_t *snap_in, uint32_t *cache_out, uint32_t *dirty, const uint32_t *changed,
+                             int first_round, hipStream_t stream);
 hipError_t launch_emit2400 (const EmitParams &p, hipStream_t stream);
 hipError_t launch_strip_offsets (const uint32_t *acc_counts, uint32_t nstrips, const uint64_t *chunk_sum, uint64_t *offsets, hipStream_t stream);
 hipError_t launch_blk_stats_sum (const uint32_t *blk_stats, uint32_t nblocks, unsigned long long *out, hipStream_t stream);

@@ -700,7 +700,7 @@ void accept_kernel (const AcceptParams p)
   if (p.dirty && !p.dirty[blk]) return;                      // same entry cache as in the round before: same results
   __builtin_amdgcn_s_setprio (3);                            // the pass is latency bound and often shares the GPU with a scan
   AcceptLds &w = lds[wv];
-  const uint32_t *entry = p.snap_in + size_t (blk) * kIcaoSlots;     // the cache as the block starts with it
+  const uint32_t *entry = p.first_round ? p.cache_in : p.snap_in + size_t (blk) * kIcaoSlots;     // the cache as the block starts with it
   for (int i = lane; i < int (kIcaoSlots); i += 64) w.cache[i] = entry[i];
   if (lane < int (kIcaoSlots / 32)) w.written[lane] = 0;
   if (lane < kBlkStats) w.counter[lane] = 0;
@@ -903,14 +903,21 @@ void accept_kernel (const AcceptParams p)
   }
   __builtin_amdgcn_s_waitcnt (0xc07f);
   __builtin_amdgcn_wave_barrier ();
-  // delta of this block + change detection against the previous round
+  // delta of this block + change detection against the previous round.  A block that wrote no slot only says so
+  // (blk_wrote): its delta row is neither written nor read.
+  const bool wrote = __ballot (lane < int (kIcaoSlots / 32) && w.written[lane & (kIcaoSlots / 32 - 1)] != 0) != 0;
+  const bool prev = !p.first_round && p.blk_wrote[blk] != 0;
   bool diff = false;
-  for (int i = lane; i < int (kIcaoSlots); i += 64) {
-    const bool wr = (w.written[i >> 5] >> (i & 31)) & 1;
-    const uint32_t nv = wr ? (kDeltaWritten | w.cache[i]) : 0u;
-    uint32_t *d = p.delta + size_t (blk) * kIcaoSlots + i;
-    if (*d != nv) { *d = nv; diff = true; }
-  }
+  if (wrote) {
+    for (int i = lane; i < int (kIcaoSlots); i += 64) {
+      const bool wr = (w.written[i >> 5] >> (i & 31)) & 1;
+      const uint32_t nv = wr ? (kDeltaWritten | w.cache[i]) : 0u;
+      uint32_t *d = p.delta + size_t (blk) * kIcaoSlots + i;
+      if (!prev) { *d = nv; diff = diff || nv != 0; }
+      else if (*d != nv) { *d = nv; diff = true; }
+    }
+  } else diff = prev;
+  if (lane == 0 && (p.first_round || prev != wrote)) p.blk_wrote[blk] = wrote ? 1u : 0u;
   if (__ballot (diff) && lane == 0) atomicOr (p.changed, 1u);
   if (lane == 0) {
     uint32_t *o = p.blk_stats + size_t (blk) * kBlkStats;
@@ -923,26 +930,37 @@ void accept_kernel (const AcceptParams p)
 // ---- propagate the per-block cache writes down the block axis ----
 constexpr int kSnapChunk = 32;
 
+// The three kernels below run behind every accept round.  `changed` is that round's word: when no delta changed (in the
+// first round: no block wrote anything) the snapshots, the dirty marks and the cache behind the last block are what
+// they were, and the kernels leave at once -- a pass over a shard without accepted squitters costs no snapshot traffic.
+
 // last write per (chunk of blocks, slot)
 __global__ __launch_bounds__ (256)
-void snap_chunk_last_kernel (const uint32_t *delta, uint32_t nblocks, uint32_t *chunk_last, uint32_t *dirty)
+void snap_chunk_last_kernel (const uint32_t *delta, const uint32_t *blk_wrote, uint32_t nblocks, uint32_t *chunk_last, uint32_t *dirty,
+                             const uint32_t *changed)
 {
+  if (!*changed) return;
   const uint32_t s = blockIdx.x * 256 + threadIdx.x, chunk = blockIdx.y;
   if (s >= kIcaoSlots) return;
   uint32_t v = 0;
   const uint32_t b0 = chunk * kSnapChunk, b1 = min (b0 + kSnapChunk, nblocks);
   if (s < kSnapChunk && b0 + s < b1) dirty[b0 + s] = 0u;             // snap_fill_kernel, next in the stream, marks the blocks to repeat
-  for (uint32_t b = b0; b < b1; b++) { const uint32_t d = delta[size_t (b) * kIcaoSlots + s]; if (d & kDeltaWritten) v = d; }
+  for (uint32_t b = b0; b < b1; b++) {
+    if (!blk_wrote[b]) continue;
+    const uint32_t d = delta[size_t (b) * kIcaoSlots + s];
+    if (d & kDeltaWritten) v = d;
+  }
   chunk_last[size_t (chunk) * kIcaoSlots + s] = v;
 }
 
 // serial over chunks, one thread per slot: cache at the entry of every chunk; also the cache after the last block
 __global__ __launch_bounds__ (256)
 void snap_chunk_scan_kernel (const uint32_t *chunk_last, uint32_t nchunks, const uint32_t *cache_in, uint32_t *chunk_entry,
-                             uint32_t *cache_out)
+                             uint32_t *cache_out, const uint32_t *changed, int first_round)
 {
   const uint32_t s = blockIdx.x * 256 + threadIdx.x;
   if (s >= kIcaoSlots) return;
+  if (!*changed) { if (first_round) cache_out[s] = cache_in[s]; return; }
   uint32_t cur = cache_in[s];
   uint32_t c = 0;
   for (; c + 8 <= nchunks; c += 8) {
@@ -964,27 +982,25 @@ void snap_chunk_scan_kernel (const uint32_t *chunk_last, uint32_t nchunks, const
 }
 
 __global__ __launch_bounds__ (256)
-void snap_fill_kernel (const uint32_t *delta, uint32_t nblocks, const uint32_t *chunk_entry, uint32_t *snap_in, uint32_t *dirty)
+void snap_fill_kernel (const uint32_t *delta, const uint32_t *blk_wrote, uint32_t nblocks, const uint32_t *chunk_entry, uint32_t *snap_in,
+                       uint32_t *dirty, const uint32_t *changed, const uint32_t *cache_in, int first_round)
 {
+  if (!*changed) return;
   const uint32_t s = blockIdx.x * 256 + threadIdx.x, chunk = blockIdx.y;
   if (s >= kIcaoSlots) return;
   uint32_t cur = chunk_entry[size_t (chunk) * kIcaoSlots + s];
+  const uint32_t first = cache_in[s];                              // what every block started from in the first round
   const uint32_t b0 = chunk * kSnapChunk, b1 = min (b0 + kSnapChunk, nblocks);
   for (uint32_t b = b0; b < b1; b++) {
     // a block whose entry cache is what it was in the round before would repeat itself: only the others run again
     uint32_t *sn = snap_in + size_t (b) * kIcaoSlots + s;
-    if (*sn != cur) { *sn = cur; dirty[b] = 1u; }
-    const uint32_t d = delta[size_t (b) * kIcaoSlots + s];
-    if (d & kDeltaWritten) cur = d & ~kDeltaWritten;
+    if (first_round) { *sn = cur; if (cur != first) dirty[b] = 1u; }
+    else if (*sn != cur) { *sn = cur; dirty[b] = 1u; }
+    if (blk_wrote[b]) {
+      const uint32_t d = delta[size_t (b) * kIcaoSlots + s];
+      if (d & kDeltaWritten) cur = d & ~kDeltaWritten;
+    }
   }
-}
-
-// snap_in[b][*] = cache_in for every block (first-round guess)
-__global__ __launch_bounds__ (256)
-void snap_broadcast_kernel (const uint32_t *cache_in, uint32_t nblocks, uint32_t *snap_in)
-{
-  const size_t i = size_t (blockIdx.x) * 256 + threadIdx.x;
-  if (i < size_t (nblocks) * kIcaoSlots) snap_in[i] = cache_in[i % kIcaoSlots];
 }
 
 // sums of the per-block statistics: out[k] = sum over blocks of blk_stats[block][k]
@@ -1406,22 +1422,15 @@ hipError_t launch_accept2400 (const AcceptParams &p, hipStream_t stream)
 }
 
 // delta -> snap_in for the next round; chunk_last/chunk_entry hold (nblocks/32 + 1) * 1024 words each
-hipError_t launch_snapshots (const uint32_t *delta, uint32_t nblocks, const uint32_t *cache_in, uint32_t *chunk_last,
-                             uint32_t *chunk_entry, uint32_t *snap_in, uint32_t *cache_out, uint32_t *dirty, hipStream_t stream)
+hipError_t launch_snapshots (const uint32_t *delta, const uint32_t *blk_wrote, uint32_t nblocks, const uint32_t *cache_in, uint32_t *chunk_last,
+                             uint32_t *chunk_entry, uint32_t *snap_in, uint32_t *cache_out, uint32_t *dirty, const uint32_t *changed,
+                             int first_round, hipStream_t stream)
 {
   if (nblocks == 0) return hipSuccess;
   const uint32_t nchunks = (nblocks + kSnapChunk - 1) / kSnapChunk;
-  hipLaunchKernelGGL (snap_chunk_last_kernel, dim3 (kIcaoSlots / 256, nchunks), dim3 (256), 0, stream, delta, nblocks, chunk_last, dirty);
-  hipLaunchKernelGGL (snap_chunk_scan_kernel, dim3 (kIcaoSlots / 256), dim3 (256), 0, stream, chunk_last, nchunks, cache_in, chunk_entry, cache_out);
-  hipLaunchKernelGGL (snap_fill_kernel, dim3 (kIcaoSlots / 256, nchunks), dim3 (256), 0, stream, delta, nblocks, chunk_entry, snap_in, dirty);
-  return hipGetLastError ();
-}
-
-hipError_t launch_snap_broadcast (const uint32_t *cache_in, uint32_t nblocks, uint32_t *snap_in, hipStream_t stream)
-{
-  if (nblocks == 0) return hipSuccess;
-  const size_t n = size_t (nblocks) * kIcaoSlots;
-  hipLaunchKernelGGL (snap_broadcast_kernel, dim3 ((unsigned) ((n + 255) / 256)), dim3 (256), 0, stream, cache_in, nblocks, snap_in);
+  hipLaunchKernelGGL (snap_chunk_last_kernel, dim3 (kIcaoSlots / 256, nchunks), dim3 (256), 0, stream, delta, blk_wrote, nblocks, chunk_last, dirty, changed);
+  hipLaunchKernelGGL (snap_chunk_scan_kernel, dim3 (kIcaoSlots / 256), dim3 (256), 0, stream, chunk_last, nchunks, cache_in, chunk_entry, cache_out, changed, first_round);
+  hipLaunchKernelGGL (snap_fill_kernel, dim3 (kIcaoSlots / 256, nchunks), dim3 (256), 0, stream, delta, blk_wrote, nblocks, chunk_entry, snap_in, dirty, changed, cache_in, first_round);
   return hipGetLastError ();
 }
 
