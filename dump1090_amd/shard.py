@@ -53,11 +53,15 @@ def decode_sharded(decode, rank, world, all_gather, initial_icao=None, max_round
     """Runs `decode(entry_state) -> (messages, exit_state)` for this rank's shard until the entry states of all ranks
     are consistent.  A state is the ICAO cache (uint32[1024]) or a dict of named parts (compared part by part).
     `all_gather(obj) -> [obj of rank 0, ...]`.  A rank whose entry state did not change keeps its result.
-    Returns (messages of this shard, rounds)."""
+    One collective per round: every rank sees every exit state, so every rank can tell by itself whether any rank's
+    entry state (= its neighbour's exit) still moved.  Ranks behind the first all start from the same guess
+    (`initial_state`, or an empty cache).  Returns (messages of this shard, rounds)."""
+    guess = initial_state if initial_state is not None else np.zeros(1024, dtype=np.uint32)
     if initial_state is not None:
         entry = initial_state
     else:
-        entry = np.zeros(1024, dtype=np.uint32) if initial_icao is None or rank > 0 else np.asarray(initial_icao, dtype=np.uint32)
+        entry = guess if initial_icao is None or rank > 0 else np.asarray(initial_icao, dtype=np.uint32)
+    entered = [guess] * world                    # what every rank decoded from in this round (rank 0's never changes)
     rounds = 0
     msgs = exit_state = None
     fresh = True
@@ -66,13 +70,15 @@ def decode_sharded(decode, rank, world, all_gather, initial_icao=None, max_round
             msgs, exit_state = decode(entry)
         rounds += 1
         exits = all_gather(exit_state)
-        new_entry = entry if rank == 0 else exits[rank - 1]
-        fresh = not _same(new_entry, entry)
-        if not any(all_gather(fresh)):
+        settled = all(_same(exits[j - 1], entered[j]) for j in range(1, world))
+        if settled:
             return msgs, rounds
         if max_rounds is not None and rounds >= max_rounds:
             raise RuntimeError("state hand-over did not settle in %d rounds" % rounds)
+        new_entry = entry if rank == 0 else exits[rank - 1]
+        fresh = not _same(new_entry, entry)
         entry = new_entry
+        entered = [entered[0]] + [exits[j - 1] for j in range(1, world)]
 
 
 def merge(per_rank_messages):
@@ -101,20 +107,35 @@ class ThreadGroup:
 
 class TorchGroup:
     """all_gather over torch.distributed (one process per GPU; backend "nccl" is RCCL on ROCm, "gloo" on CPU).  The
-    hand-over states are a few KiB: they travel as one fixed-size byte tensor per rank, flags as one int."""
+    hand-over states are a few KiB: they travel as one fixed-size byte tensor per rank, flags as one int.  The staging
+    tensors (pinned host, device) are kept per message size: a round costs two small copies and one collective."""
     D8_BYTES = 4 + 4 + 8 + 8 + 8 + 4 * 1928
 
     def __init__(self, device):
         import torch.distributed as dist
         self.dist, self.device = dist, device
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self._bufs = {}
 
     def _gather_bytes(self, blob):
         import torch
-        t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(self.device)
-        out = torch.empty(self.world * t.numel(), dtype=torch.uint8, device=self.device)
-        self.dist.all_gather_into_tensor(out, t)
-        return out.cpu().numpy().reshape(self.world, -1)
+        n = len(blob)
+        if n not in self._bufs:
+            on_gpu = str(self.device).startswith("cuda")
+            h_in = torch.empty(n, dtype=torch.uint8, pin_memory=on_gpu)
+            h_out = torch.empty(self.world * n, dtype=torch.uint8, pin_memory=on_gpu)
+            d_in = torch.empty(n, dtype=torch.uint8, device=self.device) if on_gpu else h_in
+            d_out = torch.empty(self.world * n, dtype=torch.uint8, device=self.device) if on_gpu else h_out
+            self._bufs[n] = (h_in, h_out, d_in, d_out, on_gpu)
+        h_in, h_out, d_in, d_out, on_gpu = self._bufs[n]
+        h_in.numpy()[:] = np.frombuffer(blob, dtype=np.uint8)
+        if on_gpu:
+            d_in.copy_(h_in, non_blocking=True)
+        self.dist.all_gather_into_tensor(d_out, d_in)
+        if on_gpu:
+            h_out.copy_(d_out, non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()
+        return h_out.numpy().reshape(self.world, -1).copy()
 
     def all_gather(self, obj):
         if isinstance(obj, (bool, np.bool_)):
@@ -233,8 +254,11 @@ def decode_engine_rounds(shard, rank, world, all_gather, max_rounds=None):
     if shard.rate != 8000000:
         _, rounds = decode_sharded(shard.decode, rank, world, all_gather, max_rounds=max_rounds, initial_state=shard.initial_state())
         return rounds
-    # every rank enters every collective of a round; a rank whose entry state did not change keeps its result
+    # One collective per round: the exit states travel with a flag in d8.amb_steps (a field that describes a run, not
+    # the state handed on): "this shard, behind the first, holds steps that need the running average".
+    from . import D8State
     entry = shard.initial_state()
+    entered = [entry] * world
     need_acc = with_acc = False
     fresh = True
     rounds = 0
@@ -243,17 +267,27 @@ def decode_engine_rounds(shard, rank, world, all_gather, max_rounds=None):
             _, exit_state = shard.decode(entry)
             with_acc = False
         rounds += 1
-        flags = all_gather(bool(shard.amb_steps) and rank > 0 and rounds > 1)
-        if any(flags):
-            need_acc = True
         if need_acc and not with_acc:
             exit_state = shard.exit_with_acc(exit_state)
             with_acc = True
-        exits = all_gather(exit_state)
+        st = D8State.from_buffer_copy(exit_state["d8"])
+        st.amb_steps = 1 if (shard.amb_steps and rank > 0 and rounds > 1) else 0
+        gathered = all_gather({"icao": exit_state["icao"], "d8": bytes(st)})
+        exits, asked = [], False
+        for g in gathered:
+            st = D8State.from_buffer_copy(g["d8"])
+            asked = asked or bool(st.amb_steps)
+            st.amb_steps = 0
+            exits.append({"icao": g["icao"], "d8": bytes(st)})
+        if max_rounds is not None and rounds >= max_rounds + 1:
+            raise RuntimeError("state hand-over did not settle in %d rounds" % rounds)
+        if asked and not need_acc:
+            need_acc = True                      # the states just exchanged lack the average: exchange again, with it
+            fresh = False
+            continue
+        if all(_same(exits[j - 1], entered[j]) for j in range(1, world)):
+            return rounds
         new_entry = entry if rank == 0 else exits[rank - 1]
         fresh = not _same(new_entry, entry)
-        if not any(all_gather(fresh)):
-            return rounds
-        if max_rounds is not None and rounds >= max_rounds:
-            raise RuntimeError("state hand-over did not settle in %d rounds" % rounds)
         entry = new_entry
+        entered = [entered[0]] + [exits[j - 1] for j in range(1, world)]

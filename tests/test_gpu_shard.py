@@ -175,3 +175,32 @@ def test_engine_shards_reach_the_single_pass_result(rate, fmt, world):
         c = sh.e.counters()
         if rate != 8000000:
             assert c["scan_launches"] == 1 and c["accept_passes"] == sh.rounds    # later rounds: the ordered pass only
+
+
+def test_torch_group_over_rccl_single_rank():
+    """The collective path bench.py --gpus N uses (backend "nccl" = RCCL, device tensors, pinned staging) with the one
+    rank a one-GPU box allows: states, flags and arrays come back as they went in."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        g = shard.TorchGroup("cuda:0")
+        cache = np.arange(1024, dtype=np.uint32) * 2654435761 % (1 << 24)
+        d8 = bytes(range(256)) * 30 + bytes(g.D8_BYTES - 7680)
+        for _ in range(3):                           # the staging buffers are reused
+            out = g.all_gather({"icao": cache, "d8": d8})
+            assert len(out) == 1 and np.array_equal(out[0]["icao"], cache) and out[0]["d8"] == d8
+            assert g.all_gather(True) == [True] and g.all_gather(False) == [False]
+            assert np.array_equal(g.all_gather(cache)[0], cache)
+        iq, _ = synth.capture(65536 * 3, 2.4e6, "sc16", seed=95, frames_per_sec=2500, n_icao=6)
+        d = torch.from_numpy(iq.view(np.int16)).to("cuda:0")
+        e = da.Engine(2400000, da.INPUT_SC16, fix_bits=1)
+        sh = shard.EngineShard(e, d.data_ptr(), d.numel() * 2, 0, 0, len(iq) // 2, 2400000, 4)
+        msgs, rounds = shard.decode_engine_sharded(sh, 0, 1, g.all_gather)
+        exp, _ = oracle_run(iq, "sc16")
+        assert rounds == 1
+        assert_same_messages(msgs, exp)
+    finally:
+        dist.destroy_process_group()
