@@ -50,6 +50,9 @@ class DcInfo(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
 
 
+D8_CHAIN_STATES = 168
+
+
 class D8State(C.Structure):
     """modes_d8_state: what demod_8000 carries from one shard of a recording to the next."""
     _fields_ = [("acc", C.c_int32), ("acc_valid", C.c_int32), ("pending", C.c_int64), ("trig_tail", C.c_uint64),
@@ -144,6 +147,9 @@ def lib():
         L.modes_engine_get_power_stats.argtypes = [C.c_void_p, C.POINTER(PowerStats)]
         L.modes_engine_set_d8_state.argtypes = [C.c_void_p, C.POINTER(D8State)]
         L.modes_engine_get_d8_state.argtypes = [C.c_void_p, C.POINTER(D8State), C.c_int, C.c_void_p]
+        L.modes_engine_d8_chain_map.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint64, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+        L.modes_engine_d8_reuse_planes.argtypes = [C.c_void_p]
+        L.modes_engine_d8_last_ambiguous.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.modes_engine_decode_fields.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_void_p]
         L.modes_decode_fields_host.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.modes_live_open.argtypes = [C.POINTER(EngineConfig), C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
@@ -275,6 +281,23 @@ class Engine:
         s = D8State()
         _check(self.L.modes_engine_get_d8_state(self.h, C.byref(s), int(want_acc), C.c_void_p(stream) if stream else None))
         return s
+
+    def d8_chain_map(self, data_ptr, nbytes, first_sample=0, halo_ptr=None, stream=None):
+        """int32[168]: the `pending` the shard hands on for every `pending` it can be entered with (index 0: none,
+        index i: -i).  Keeps the state set with set_d8_state() and the trigger planes for the run that follows."""
+        m = (C.c_int32 * D8_CHAIN_STATES)()
+        _check(self.L.modes_engine_d8_chain_map(self.h, C.c_void_p(data_ptr), nbytes, first_sample,
+                                                C.c_void_p(halo_ptr) if halo_ptr else None,
+                                                C.c_void_p(stream) if stream else None, m))
+        return np.frombuffer(m, dtype=np.int32).copy()
+
+    def d8_last_ambiguous(self):
+        v = C.c_uint64()
+        _check(self.L.modes_engine_d8_last_ambiguous(self.h, C.byref(v)))
+        return v.value
+
+    def d8_reuse_planes(self):
+        _check(self.L.modes_engine_d8_reuse_planes(self.h))
 
     def run_host(self, iq, first_sample=0):
         iq = np.ascontiguousarray(iq)

@@ -660,6 +660,7 @@ static bool demod_8000_locked (const mag_buf *mag, uint32_t block)
   HIP_OK (hipMemsetAsync (q.amb, 0, words * sizeof (uint64_t), nullptr));
   HIP_OK (launch_d8_trig (q, 0, nullptr));
   HIP_OK (launch_d8_acc (q, nsteps, d_acc, nullptr));           // the running average is carried to the next call: always formed
+  HIP_OK (launch_d8_chain_table (q, nullptr));
   HIP_OK (launch_d8_chain (q, s.trig_tail, 0ll, d_pre, d_pending, nullptr));
   HIP_OK (launch_d8_windows (q, q.nchunks, nullptr));
   HIP_OK (launch_d8_tail (q, s.dnext, nullptr));

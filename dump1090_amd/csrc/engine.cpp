@@ -136,6 +136,12 @@ int select_converter (int fmt, bool dc, bool power)
 
 }  // namespace
 
+struct D8PlanesKey {
+  const void *iq = nullptr; size_t nbytes = 0; uint64_t first_sample = 0; const void *halo = nullptr; bool have_in = false; int32_t acc0 = 0;
+  bool operator== (const D8PlanesKey &o) const
+  { return iq == o.iq && nbytes == o.nbytes && first_sample == o.first_sample && halo == o.halo && have_in == o.have_in && acc0 == o.acc0; }
+};
+
 struct modes_engine {
   modes_engine_config cfg;
   int conv = -1;
@@ -234,6 +240,18 @@ struct modes_engine {
   uint64_t d8_amb_steps = 0, d8_limit = 0;
   unsigned long long d8_trig_tail_in = 0;
   D8Params d8_q;
+  // trigger planes / chunk tables of the last 8 MS/s call and what they were formed from (see run_8000)
+  D8PlanesKey d8_planes_key;
+  int32_t d8_planes_dprev[1928];
+  unsigned long long d8_planes_limit = 0;
+  bool d8_planes_valid = false, d8_reuse = false, d8_planes_timed = true;
+  // the windows (and what they announced) of the last full run: formed from planes generation d8_win_gen, entered with
+  // this open window / trigger history.  A run on the same planes with the same entry only repeats what hangs on the
+  // ICAO cache: count, gather, the host's walk.
+  uint64_t d8_planes_gen = 0, d8_win_gen = ~0ull;
+  long long d8_win_pending = 0;
+  unsigned long long d8_win_tail = 0;
+  DevBuf<int32_t> d8_exit_of;
   bool d8_have_run = false, d8_passthrough = false;
 };
 
@@ -838,7 +856,7 @@ void modes_engine_destroy (modes_engine *e)
   e->d8_win_count.release (); e->d8_chunk_rec.release (); e->d8_announce.release (); e->d8_table.release (); e->d8_entry.release ();
   e->d8_win_start.release (); e->d8_small.release (); e->d8_windows.release (); e->d8_win_packed.release ();
   e->d8_records.release (); e->d8_rec_packed.release (); e->dirty.release (); e->blk_wrote.release (); e->rb.release (); e->pin_rb.release (); e->pin_sums.release (); e->pin_tot.release (); e->d8_tot.release (); e->pin_wins2.release (); e->pin_recs2.release (); e->pin_rpos.release (); e->pin_rlen.release ();
-  e->d8_dprev.release (); e->d8_dnext.release (); e->pin_d8.release ();
+  e->d8_dprev.release (); e->d8_dnext.release (); e->pin_d8.release (); e->d8_exit_of.release ();
   e->d_fields.release (); e->pin_fields.release ();
   if (e->post_stream) (void) hipStreamDestroy (e->post_stream);
   if (e->copy_stream) (void) hipStreamDestroy (e->copy_stream);
@@ -1115,8 +1133,11 @@ static int run_mode_ac_2400 (modes_engine *e, const void *d_iq, size_t nbytes, u
 }
 
 // demod_8000 over a whole recording (ref: src/demod-8000.c:143-523); see kernels_8000.hip for the decomposition.
+// chain_map (modes_engine_d8_chain_map): stop behind the trigger planes and the chunk tables and report where the
+// window chain leaves the shard for every state it can be entered in; nothing is decoded and the state set for the run
+// stays set.
 static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t first_sample, const uint16_t *d_halo,
-                     hipStream_t stream)
+                     hipStream_t stream, int32_t *chain_map = nullptr)
 {
   if (first_sample % e->block_samples && nbytes / bytes_per_sample (e->cfg.input_format) > e->block_samples)
     return fail (MODES_E_ARG, "first_sample must be a multiple of the block length");
@@ -1145,7 +1166,7 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   q.acc0 = 0; q.pending = 1;
   // what the shard before left (ref: src/demod-8000.c:80-89,186-220): one run only
   const bool have_in = e->d8_in_set;
-  e->d8_in_set = false;
+  if (!chain_map) e->d8_in_set = false;
   e->d8_out_acc_valid = false;
   e->d8_amb_steps = 0;
   e->d8_have_run = false;
@@ -1159,8 +1180,10 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
     q.dprev = e->d8_dprev.p;
     q.acc0 = e->d8_in.acc; q.pending = e->d8_in.pending; trig_tail_in = e->d8_in.trig_tail;
   }
-  e->tail_half ^= 1;
-  HIP_TRY (launch_tail (sp, sp.nsamples, e->tail.p + e->tail_half * ((e->ov + 7u) & ~7u), stream));   // what a following shard needs as d_halo
+  if (!chain_map) {
+    e->tail_half ^= 1;
+    HIP_TRY (launch_tail (sp, sp.nsamples, e->tail.p + e->tail_half * ((e->ov + 7u) & ~7u), stream));   // what a following shard needs as d_halo
+  }
   if (q.nsteps == 0) {
     if (have_in) { e->d8_out = e->d8_in; e->d8_out_acc_valid = e->d8_in.acc_valid != 0; e->d8_have_run = true; e->d8_passthrough = true; }
     return MODES_OK;
@@ -1189,34 +1212,87 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   long long *d_pending = d_pre + 4;
   q.amb_count = reinterpret_cast<uint32_t *> (d_pre + 5);
   unsigned long long *d_limit = reinterpret_cast<unsigned long long *> (d_pre + 6);
-  const long long init[8] = { 0, 0, 0, 0, 1, 0, 0, 0 };
-  HIP_TRY (hipMemcpyAsync (d_pre, init, sizeof init, hipMemcpyHostToDevice, stream));
-  HIP_TRY (hipMemsetAsync (q.trig, 0, nwords * sizeof (uint64_t), stream));
-  HIP_TRY (hipMemsetAsync (q.amb, 0, nwords * sizeof (uint64_t), stream));
-  HIP_TRY (hipEventRecord (e->ev[2], stream));
-  HIP_TRY (launch_d8_trig (q, 0, stream));
-  HIP_TRY (hipEventRecord (e->ev[3], stream));
-  HIP_TRY (launch_d8_last_amb (q.amb, nwords, d_limit, stream));
+  // The trigger planes and the chunk tables are functions of the samples, the differences carried in and (on near-silent
+  // input) the running average carried in -- not of where the window chain enters.  A caller that promises the samples
+  // are those of the call before (modes_engine_d8_chain_map, modes_engine_d8_reuse_planes) gets them reused.
+  D8PlanesKey key;
+  key.iq = d_iq; key.nbytes = nbytes; key.first_sample = first_sample; key.halo = d_halo; key.have_in = have_in; key.acc0 = q.acc0;
+  const bool reuse = e->d8_reuse && !e->cfg.filter_dc && e->d8_planes_valid && key == e->d8_planes_key &&
+                     (!have_in || !memcmp (e->d8_planes_dprev, e->d8_in.dprev, sizeof e->d8_planes_dprev));
+  e->d8_reuse = false;
+  e->d8_planes_valid = false;
   unsigned long long limit = 0;
-  HIP_TRY (hipMemcpyAsync (&limit, d_limit, sizeof limit, hipMemcpyDeviceToHost, stream));
-  HIP_TRY (hipStreamSynchronize (stream));
-  if (limit && have_in && !e->d8_in.acc_valid)
-    return fail (MODES_E_ARG, "demod_8000: this shard holds steps whose trigger depends on the running average (near-silent input): "
-                              "the state handed over must carry acc (modes_engine_get_d8_state with want_acc)");
-  if (limit) {
-    // some steps sit in the band where the trigger depends on the running average: form it, in order, up to the last one
-    if ((rc = e->d8_p0.reserve (size_t (q.nsteps) + 64)) != MODES_OK) return rc;
-    if ((rc = e->d8_mx.reserve (size_t (q.nsteps) + 64)) != MODES_OK) return rc;
-    q.p0 = e->d8_p0.p; q.mx = e->d8_mx.p; q.write_arrays = 1;
-    HIP_TRY (launch_d8_trig (q, limit, stream));                  // only the strips up to the last such step
-    q.write_arrays = 0;
-    HIP_TRY (launch_d8_acc (q, limit, nullptr, stream));
+  // Same planes and same entry of the window chain as the run before (a hand-over round in which only the ICAO cache
+  // moved): the windows, their candidate records and what they announced stand.
+  const bool same_windows = reuse && !chain_map && e->d8_win_gen == e->d8_planes_gen && e->d8_win_pending == (long long) q.pending &&
+                            e->d8_win_tail == trig_tail_in;
+  if (!chain_map) e->d8_win_gen = ~0ull;
+  if (reuse) {
+    const long long init[5] = { 0, 0, 0, 0, 1 };                  // the pre-window list and the open window; counts and planes stay
+    if (!same_windows) HIP_TRY (hipMemcpyAsync (d_pre, init, sizeof init, hipMemcpyHostToDevice, stream));
+    limit = e->d8_planes_limit;
+    e->kernel_ms[1] = 0;
+  } else {
+    const long long init[8] = { 0, 0, 0, 0, 1, 0, 0, 0 };
+    HIP_TRY (hipMemcpyAsync (d_pre, init, sizeof init, hipMemcpyHostToDevice, stream));
+    HIP_TRY (hipMemsetAsync (q.trig, 0, nwords * sizeof (uint64_t), stream));
+    HIP_TRY (hipMemsetAsync (q.amb, 0, nwords * sizeof (uint64_t), stream));
+    HIP_TRY (hipEventRecord (e->ev[2], stream));
+    HIP_TRY (launch_d8_trig (q, 0, stream));
+    HIP_TRY (hipEventRecord (e->ev[3], stream));
+    HIP_TRY (launch_d8_last_amb (q.amb, nwords, d_limit, stream));
+    HIP_TRY (hipMemcpyAsync (&limit, d_limit, sizeof limit, hipMemcpyDeviceToHost, stream));
+    HIP_TRY (hipStreamSynchronize (stream));
+    if (limit && have_in && !e->d8_in.acc_valid)
+      return fail (MODES_E_ARG, "demod_8000: this shard holds steps whose trigger depends on the running average (near-silent input): "
+                                "the state handed over must carry acc (modes_engine_get_d8_state with want_acc)");
+    if (limit) {
+      // some steps sit in the band where the trigger depends on the running average: form it, in order, up to the last one
+      if ((rc = e->d8_p0.reserve (size_t (q.nsteps) + 64)) != MODES_OK) return rc;
+      if ((rc = e->d8_mx.reserve (size_t (q.nsteps) + 64)) != MODES_OK) return rc;
+      q.p0 = e->d8_p0.p; q.mx = e->d8_mx.p; q.write_arrays = 1;
+      HIP_TRY (launch_d8_trig (q, limit, stream));                  // only the strips up to the last such step
+      q.write_arrays = 0;
+      HIP_TRY (launch_d8_acc (q, limit, nullptr, stream));
+    }
+    HIP_TRY (launch_d8_chain_table (q, stream));
+    e->d8_planes_gen++;
   }
+  e->d8_planes_key = key; e->d8_planes_limit = limit;
+  if (have_in) memcpy (e->d8_planes_dprev, e->d8_in.dprev, sizeof e->d8_planes_dprev);
+  e->d8_planes_timed = !reuse;
+  if (chain_map) {
+    if (limit && first_sample != 0)
+      return fail (MODES_E_ARG, "modes_engine_d8_chain_map: this shard holds steps whose trigger depends on the running average "
+                                "(near-silent input), which depends on every shard before it");
+    // map[i]: the window left open behind the shard when it is entered with pending = (i ? -i : 1)
+    if ((rc = e->d8_exit_of.reserve (128)) != MODES_OK) return rc;
+    int32_t exit_of[kD8Net];
+    HIP_TRY (launch_d8_chain_exit (q, e->d8_exit_of.p, stream));
+    HIP_TRY (hipMemcpyAsync (exit_of, e->d8_exit_of.p, sizeof exit_of, hipMemcpyDeviceToHost, stream));
+    HIP_TRY (hipStreamSynchronize (stream));
+    for (int i = 0; i < MODES_D8_CHAIN_STATES; i++) {
+      // what d8_chain_resolve_kernel does in front of step 0 (ref: src/demod-8000.c:493-496 re-scans the last steps)
+      long long pos = 0;
+      if (i) pos = -(long long) i + kD8Net;
+      while (pos < 0) {
+        const int b = int (pos + 64);
+        const unsigned long long word = b >= 0 ? trig_tail_in & (~0ull << b) : trig_tail_in;
+        if (!word) { pos = 0; break; }
+        pos = (long long) __builtin_ctzll (word) - 64 + kD8Net;
+      }
+      chain_map[i] = exit_of[pos < kD8Net - 1 ? pos : kD8Net - 1];
+    }
+    e->d8_planes_valid = true;                                     // the run that follows on the same samples starts from them
+    e->d8_reuse = true;
+    return MODES_OK;
+  }
+  e->d8_planes_valid = true;
   // addresses the run can know: what the cache starts with, plus every address the window kernel sees announced
   q.announce = e->d8_announce.p;
   {
     // the bitmap is cleared on the device; only the addresses the starting cache holds travel (4 KB)
-    HIP_TRY (hipMemsetAsync (q.announce, 0, ((1u << 24) / 32) * sizeof (uint32_t), stream));
+    if (!same_windows) HIP_TRY (hipMemsetAsync (q.announce, 0, ((1u << 24) / 32) * sizeof (uint32_t), stream));
     if ((rc = e->pin_bits.reserve (kIcaoSlots)) != MODES_OK) return rc;
     if ((rc = e->small_u32.reserve (2 * kIcaoSlots + 16)) != MODES_OK) return rc;
     uint32_t nseed = 0;
@@ -1227,7 +1303,7 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
       HIP_TRY (launch_d8_seed (q.announce, e->small_u32.p, nseed, stream));
     }
   }
-  HIP_TRY (launch_d8_chain (q, trig_tail_in, 0ll, d_pre, d_pending, stream));
+  if (!same_windows) HIP_TRY (launch_d8_chain (q, trig_tail_in, 0ll, d_pre, d_pending, stream));
   {
     // what this run leaves for the shard behind it: the last 1928 differences, the open window, the last 64 trigger
     // decisions (read back with the first range's counts below); acc only on request (modes_engine_get_d8_state)
@@ -1294,7 +1370,7 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
     const uint32_t c0 = lo[r], n = lo[r + 1] - c0;
     q.chunk0 = c0;
     HIP_TRY (hipEventRecord (e->d8_events[3 * r], stream));
-    HIP_TRY (launch_d8_windows (q, n, stream));
+    if (!same_windows) HIP_TRY (launch_d8_windows (q, n, stream));
     HIP_TRY (hipEventRecord (e->d8_events[3 * r + 1], stream));
     HIP_TRY (launch_d8_count (q, n, e->d8_chunk_rec.p, stream));
     HIP_TRY (launch_d8_offsets (e->d8_chunk_rec.p, e->d8_win_count.p, nchunks, c0, n, e->d8_off.p, e->d8_off.p + nchunks + 1,
@@ -1318,7 +1394,7 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   for (uint32_t r = 0; r < nranges; r++) {
     const uint32_t c0 = lo[r], c1 = lo[r + 1];
     HIP_TRY (hipEventSynchronize (e->d8_gathered[r]));
-    if (r == 0) (void) hipEventElapsedTime (&e->kernel_ms[1], e->ev[2], e->ev[3]);
+    if (r == 0 && e->d8_planes_timed) (void) hipEventElapsedTime (&e->kernel_ms[1], e->ev[2], e->ev[3]);
     float wms = 0;
     (void) hipEventElapsedTime (&wms, e->d8_events[3 * r], e->d8_events[3 * r + 1]);
     e->kernel_ms[0] += wms;
@@ -1390,6 +1466,7 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   }
   HIP_TRY (hipStreamSynchronize (lvl));
   HIP_TRY (hipStreamSynchronize (stream));
+  e->d8_win_gen = e->d8_planes_gen; e->d8_win_pending = (long long) q.pending; e->d8_win_tail = trig_tail_in;
   e->d8_last_chunks = nchunks; e->d8_last_nwin = all_win; e->d8_last_nrec = all_rec; e->d8_last_msgs = e->messages.size ();
   for (const LevelOf &lv : level_of)
     e->messages[lv.msg].sig_level = (double (e->pin_sums.p[lv.sum]) / 65535.0 / 65535.0) / double (lv.len);
@@ -1452,6 +1529,32 @@ int modes_engine_rerun_accept (modes_engine *e, void *stream_v)
   e->stats.scan_retries = retries;
   (void) cand;
   return run_accept_on_device (e, e->last_sp, e->last_first_sample, stream, false);
+}
+
+int modes_engine_d8_chain_map (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t first_sample, const uint16_t *d_halo,
+                               void *stream_v, int32_t *map)
+{
+  if (!e || !map || (!d_iq && nbytes)) return fail (MODES_E_ARG, "null argument");
+  if (e->mode != 8000) return fail (MODES_E_ARG, "modes_engine_d8_chain_map: not an 8 MS/s engine");
+  if (nbytes / bytes_per_sample (e->cfg.input_format) < 8u * kD8Win)
+    return fail (MODES_E_ARG, "modes_engine_d8_chain_map: the shard is shorter than a match window");
+  return run_8000 (e, d_iq, nbytes, first_sample, d_halo, static_cast<hipStream_t> (stream_v), map);
+}
+
+int modes_engine_d8_last_ambiguous (const modes_engine *e, uint64_t *step_plus_1)
+{
+  if (!e || !step_plus_1) return fail (MODES_E_ARG, "null argument");
+  if (e->mode != 8000) return fail (MODES_E_ARG, "modes_engine_d8_last_ambiguous: not an 8 MS/s engine");
+  *step_plus_1 = e->d8_limit;
+  return MODES_OK;
+}
+
+int modes_engine_d8_reuse_planes (modes_engine *e)
+{
+  if (!e) return fail (MODES_E_ARG, "null engine");
+  if (e->mode != 8000) return fail (MODES_E_ARG, "modes_engine_d8_reuse_planes: not an 8 MS/s engine");
+  e->d8_reuse = true;
+  return MODES_OK;
 }
 
 int modes_engine_set_d8_state (modes_engine *e, const modes_d8_state *in)

@@ -22,6 +22,8 @@ hipError_t upload_constants_8000 (const uint32_t *single_bit, const float *uc8_f
 hipError_t launch_d8_trig (const D8Params &q, uint64_t step_limit, hipStream_t stream);
 hipError_t launch_d8_acc (const D8Params &q, uint64_t limit, int32_t *acc_out, hipStream_t stream);
 hipError_t launch_d8_last_amb (const uint64_t *amb, uint64_t nwords, unsigned long long *limit, hipStream_t stream);
+hipError_t launch_d8_chain_table (const D8Params &q, hipStream_t stream);
+hipError_t launch_d8_chain_exit (const D8Params &q, int32_t *exit_of, hipStream_t stream);
 hipError_t launch_d8_chain (const D8Params &q, unsigned long long trig_tail, long long search0, long long *pre,
                             long long *pending_out, hipStream_t stream);
 hipError_t launch_d8_windows (const D8Params &q, uint32_t nch, hipStream_t stream);   // chunks q.chunk0 .. + nch

@@ -272,6 +272,42 @@ void d8_chain_resolve_kernel (const D8Params q, u64 trig_tail, long long search0
   }
 }
 
+// Where the chain leaves the shard for every offset it can enter it at: exit_of[e] = start (< 0, relative to the end
+// of the shard) of the window still open when the samples end, or 1 = none.  What a rank needs to tell the ranks behind
+// it before anybody knows where the chain really enters (modes_engine_d8_chain_map).  One workgroup, thread = entry
+// offset; chunks that end a window's length before the end of the shard go through their tables, the rest is walked.
+__global__ __launch_bounds__ (128)
+void d8_chain_exit_kernel (const D8Params q, int32_t *exit_of)
+{
+  __shared__ __attribute__ ((aligned (16))) uint8_t tab[128 * 128];
+  __shared__ u64 bm[kD8ChunkSteps / 64 + 8];
+  const int r = threadIdx.x;
+  uint32_t e = r < kD8Net ? uint32_t (r) : 0u;
+  const uint64_t nsafe64 = q.nsteps >= uint64_t (kD8Win) ? (q.nsteps - kD8Win) / kD8ChunkSteps : 0;
+  const uint32_t nsafe = uint32_t (min (nsafe64, uint64_t (q.nchunks)));
+  for (uint32_t base = 0; base < nsafe; base += 128) {
+    const uint32_t n = min (128u, nsafe - base);
+    const uint4 *src = reinterpret_cast<const uint4 *> (q.table + size_t (base) * 128);
+    for (uint32_t i = threadIdx.x; i < n * 8; i += 128) reinterpret_cast<uint4 *> (tab)[i] = src[i];
+    __syncthreads ();
+    for (uint32_t c = 0; c < n; c++) e = tab[c * 128 + e];
+    __syncthreads ();
+  }
+  const long long n_lo = (long long) nsafe * kD8ChunkSteps, len = (long long) q.nsteps - n_lo;     // < one chunk + one window
+  const int nwords = int ((len + 63) >> 6);
+  for (int i = threadIdx.x; i < nwords; i += 128) bm[i] = q.trig[(n_lo >> 6) + i];
+  __syncthreads ();
+  int32_t out = 1;
+  long long pos = e;
+  while (pos < len) {
+    const long long s = first_trig (bm, nwords, pos);
+    if (s < 0) break;
+    if (s + kD8Win > len) { out = int32_t (s - len); break; }    // the samples end inside this window: nothing opens behind it
+    pos = s + kD8Net;
+  }
+  if (r < kD8Net) exit_of[r] = out;
+}
+
 // per chunk: the window openings themselves; the last one may still be open when the stream ends
 __global__ __launch_bounds__ (64)
 void d8_chain_walk_kernel (const D8Params q, const long long *pre, long long *pending_out)
@@ -720,10 +756,22 @@ hipError_t launch_d8_acc (const D8Params &q, uint64_t limit, int32_t *acc_out, h
   return hipGetLastError ();
 }
 
+hipError_t launch_d8_chain_table (const D8Params &q, hipStream_t stream)
+{
+  if (q.nchunks) hipLaunchKernelGGL (d8_chain_table_kernel, dim3 (q.nchunks), dim3 (128), 0, stream, q);
+  return hipGetLastError ();
+}
+
+hipError_t launch_d8_chain_exit (const D8Params &q, int32_t *exit_of, hipStream_t stream)
+{
+  hipLaunchKernelGGL (d8_chain_exit_kernel, dim3 (1), dim3 (128), 0, stream, q, exit_of);
+  return hipGetLastError ();
+}
+
+// behind launch_d8_chain_table
 hipError_t launch_d8_chain (const D8Params &q, unsigned long long trig_tail, long long search0, long long *pre,
                             long long *pending_out, hipStream_t stream)
 {
-  if (q.nchunks) hipLaunchKernelGGL (d8_chain_table_kernel, dim3 (q.nchunks), dim3 (128), 0, stream, q);
   hipLaunchKernelGGL (d8_chain_resolve_kernel, dim3 (1), dim3 (256), 0, stream, q, (u64) trig_tail, search0, pre);
   if (q.nchunks) hipLaunchKernelGGL (d8_chain_walk_kernel, dim3 (q.nchunks), dim3 (64), 0, stream, q, pre, pending_out);
   return hipGetLastError ();

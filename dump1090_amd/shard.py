@@ -18,7 +18,13 @@ practice two.  At 2.0 / 2.4 MS/s the scan kernel's records do not depend on the 
 repeat only the ordered accept pass (`modes_engine_rerun_accept`).  No data-path collective: only the states and
 the (small) message lists travel.
 """
+import ctypes
+
 import numpy as np
+
+
+def C_memmove(dst, src):
+    ctypes.memmove(dst, src, ctypes.sizeof(dst))
 
 
 def plan_shards(nsamples, block_samples, world):
@@ -182,6 +188,60 @@ class EngineShard:
         self.scanned = False
         self.rounds = 0
         self.amb_steps = 0
+        self.entry_states = None                                    # set by settle_chain()
+
+    def settle_chain(self, rank, world, all_gather):
+        """8 MS/s: where the window chain enters every shard, before anything is decoded (one collective).
+
+        The differences and the trigger history in front of a shard are functions of the samples in front of it: the
+        rank forms them from the block it holds there (decoded as a stream of its own).  Only `pending`, the window
+        left open by the shard before, depends on all earlier shards, and through 168 possible values: every rank
+        reports what it would hand on for each (`modes_engine_d8_chain_map`) and follows the maps from the stream's
+        start.  Returns the entry states of all ranks, or None when near-silent input makes the trigger depend on the
+        running average (then the states are found by rounds, decode_engine_rounds)."""
+        from . import D8State, D8_CHAIN_STATES, ModesError
+        e = self.e
+        block = 262144 // self.bps
+        local = D8State()
+        local.pending, local.acc_valid = 1, 1
+        ok = True
+        if self.first:
+            e.set_icao(None)
+            e.run_device(self.ptr - block * self.bps, block * self.bps, first_sample=0, stream=self.stream)
+            s = e.get_d8_state(want_acc=False, stream=self.stream)
+            # the block starts cold (no differences in front of it), which only its first steps feel; what is read here
+            # are its last 64 trigger decisions: they must not hang on the running average
+            ok = e.d8_last_ambiguous() <= block // 8 - 64
+            local.trig_tail = s.trig_tail
+            C_memmove(local.dprev, s.dprev)
+            e.set_icao(None)
+        cmap = np.zeros(D8_CHAIN_STATES, dtype=np.int32)
+        if ok and self.count:
+            halo = None
+            if self.first:
+                e.halo_at(self.buf_ptr, self.buf_nbytes, self.lead, self.halo.data_ptr(), stream=self.stream)
+                halo = self.halo.data_ptr()
+                e.set_d8_state(local)
+            try:
+                cmap = e.d8_chain_map(self.ptr, self.count * self.bps, first_sample=self.first, halo_ptr=halo, stream=self.stream)
+            except ModesError:
+                ok = False
+        elif ok:                                                     # an empty shard hands on what it gets
+            cmap = np.array([1] + [-i for i in range(1, D8_CHAIN_STATES)], dtype=np.int32)
+        blob = np.concatenate([np.array([int(ok)], dtype=np.int32), cmap]).view(np.uint8)
+        rows = all_gather(np.concatenate([blob, np.frombuffer(bytes(local), dtype=np.uint8)]))
+        if not all(int(r[:4].view(np.int32)[0]) for r in rows):
+            e.set_d8_state(None)
+            return None
+        states, pending = [], 1
+        for j in range(world):
+            st = D8State.from_buffer_copy(rows[j][4 + 4 * D8_CHAIN_STATES:].tobytes())
+            st.pending, st.acc, st.acc_valid, st.amb_steps = pending, 0, 1, 0
+            states.append({"icao": np.zeros(1024, dtype=np.uint32), "d8": bytes(st)})
+            m = rows[j][4:4 + 4 * D8_CHAIN_STATES].view(np.int32)
+            pending = int(m[0 if pending == 1 else -pending])
+        self.entry_states = states
+        return states
 
     def initial_state(self):
         st = {"icao": np.zeros(1024, dtype=np.uint32)}
@@ -207,6 +267,8 @@ class EngineShard:
                 halo = self.halo.data_ptr()
             if self.rate == 8000000 and self.first:
                 e.set_d8_state(D8State.from_buffer_copy(entry["d8"]))
+            if self.rate == 8000000 and (self.scanned or self.entry_states is not None):
+                e.d8_reuse_planes()                                  # same samples as the call before: the trigger planes stand
             e.run_device(self.ptr, self.count * self.bps, first_sample=self.first, halo_ptr=halo, stream=self.stream)
             self.scanned = True
         out = {"icao": e.get_icao()}
@@ -257,8 +319,12 @@ def decode_engine_rounds(shard, rank, world, all_gather, max_rounds=None):
     # One collective per round: the exit states travel with a flag in d8.amb_steps (a field that describes a run, not
     # the state handed on): "this shard, behind the first, holds steps that need the running average".
     from . import D8State
-    entry = shard.initial_state()
-    entered = [entry] * world
+    states = shard.settle_chain(rank, world, all_gather)
+    if states is None:                               # near-silent input: guesses, and a round per shard if it comes to that
+        entry = shard.initial_state()
+        entered = [entry] * world
+    else:
+        entry, entered = states[rank], states
     need_acc = with_acc = False
     fresh = True
     rounds = 0

@@ -271,6 +271,22 @@ typedef struct modes_d8_state {
   int32_t  dprev[1928];
 } modes_d8_state;
 int  modes_engine_set_d8_state (modes_engine *e, const modes_d8_state *in);      /* applies to the next run only */
+/* Sharded 8 MS/s decode without a round per shard.  Where the window chain enters a shard depends on every shard before
+ * it (where the input is never silent, windows follow each other at 113 steps and never re-synchronise), but only
+ * through `pending`; the differences and the trigger history in front of a shard are functions of the samples in front
+ * of it.  modes_engine_d8_chain_map() forms the shard's trigger planes (with the dprev / trig_tail / acc of the state
+ * set for the run, which stays set) and reports, for each of the MODES_D8_CHAIN_STATES values `pending` can enter with
+ * -- index 0: none, index i: -i -- the `pending` the shard would hand on.  The ranks exchange their maps once and each
+ * follows them from the stream's start to its own entry (dump1090_amd/shard.py).  The planes are kept for the run that
+ * follows on the same samples; modes_engine_d8_reuse_planes() makes the same promise for a repeated run (same d_iq,
+ * nbytes, first_sample, d_halo and differences carried in: only then is anything reused).
+ * No counterpart in the reference, which is one sequential stream (ref: src/demod-8000.c:80-89,493-522). */
+#define MODES_D8_CHAIN_STATES 168
+int  modes_engine_d8_chain_map (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t first_sample, const uint16_t *d_halo,
+                                void *stream, int32_t map[MODES_D8_CHAIN_STATES]);
+int  modes_engine_d8_reuse_planes (modes_engine *e);
+/* 1 + the last step of the last 8 MS/s run whose trigger depended on the running average (0: none did); steps = samples / 8. */
+int  modes_engine_d8_last_ambiguous (const modes_engine *e, uint64_t *step_plus_1);
 int  modes_engine_get_d8_state (modes_engine *e, modes_d8_state *out, int want_acc, void *stream);
 
 /* Field decode of the last run's messages, batched on the device: what decode_mode_S_message() does behind its CRC /

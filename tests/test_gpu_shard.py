@@ -139,12 +139,17 @@ def _run_ranks(world, make_shard):
 
 
 @pytest.mark.parametrize("rate,fmt,world", [(2400000, "sc16", 3), (2000000, "sc16", 2), (2400000, "uc8lut", 2), (8000000, "sc16", 3),
-                                            (8000000, "quiet", 3)])
+                                            (8000000, "quiet", 3), (8000000, "noisy", 4)])
 def test_engine_shards_reach_the_single_pass_result(rate, fmt, world):
     """The product path of a sharded decode: every rank holds only its shard and one block in front of it, forms its
     own halo, and the entry states (ICAO cache; at 8 MS/s also demod_8000's carried state) are handed over until they
     settle.  From the second round on no scan kernel runs at 2.0 / 2.4 MS/s."""
-    if rate == 8000000:
+    if rate == 8000000 and fmt == "noisy":
+        # receiver noise everywhere: demod_8000's trigger never pauses, windows follow each other at 113 steps and where
+        # they fall depends on where the chain entered the shard
+        iq, _ = synth.capture(65536 * 11 + 777, 8e6, "sc16", seed=97, frames_per_sec=1500, ap_fraction=0.3, n_icao=6)
+        efmt, bps, ofmt = da.INPUT_SC16, 4, "sc16"
+    elif rate == 8000000:
         iq = _capture_8000(nblocks=9, quiet=fmt == "quiet")
         efmt, bps, ofmt = da.INPUT_SC16, 4, "sc16"
     elif fmt == "uc8lut":
@@ -171,10 +176,22 @@ def test_engine_shards_reach_the_single_pass_result(rate, fmt, world):
     assert len(exp) > 40
     rounds = res[0][1]
     assert 2 <= rounds <= (world + 1 if fmt != "quiet" else 2 * world + 2)
-    for _, _, sh in res:
+    assert len(exp) > (100 if fmt == "noisy" else 40)
+    for r, (_, _, sh) in enumerate(res):
         c = sh.e.counters()
         if rate != 8000000:
             assert c["scan_launches"] == 1 and c["accept_passes"] == sh.rounds    # later rounds: the ordered pass only
+        elif fmt == "noisy":
+            # the window chain was settled before anything was decoded (modes_engine_d8_chain_map): what rank r - 1
+            # left behind its shard is what rank r was entered with -- differences, trigger history, open window
+            assert sh.entry_states is not None and rounds <= 3
+            if r:
+                left = da.D8State.from_buffer_copy(res[r - 1][2]._d8_exit(None))
+                had = da.D8State.from_buffer_copy(sh.entry_states[r]["d8"])
+                assert (left.pending, left.trig_tail) == (had.pending, had.trig_tail)
+                assert bytes(left.dprev) == bytes(had.dprev)
+        elif fmt == "quiet":
+            assert sh.entry_states is None        # near-silent input: the trigger needs the running average, rounds find the states
 
 
 def test_torch_group_over_rccl_single_rank():
