@@ -13,7 +13,10 @@ constexpr uint32_t kNonIcao = 1u << 24;              // ref: src/misc.h:699
 enum Conv : int {
   kConvUc8Lut = 0, kConvUc8LutPower = 1, kConvUc8Generic = 2,
   kConvSc16Int = 3, kConvSc16Generic = 4, kConvSc16Q11Generic = 5,
-  kConvMagU16 = 6     // not a converter: the input already is the uint16 magnitude buffer of a mag_buf
+  kConvMagU16 = 6,    // not a converter: the input already is the uint16 magnitude buffer of a mag_buf
+  // scan2400_kernel only: kConvUc8Lut with the LDS tile holding, per sample, the rank of its magnitude among the byte
+  // table's values (one byte instead of two: half the LDS, more waves per SIMD); magnitudes are looked up where needed
+  kConvUc8LutR8 = 7
 };
 
 // ---- scan kernel geometry (2.4 MS/s) -------------------------------------------------
@@ -116,6 +119,11 @@ struct ScanParams {
   const uint32_t *noise_level;     // [blocks]: (unsigned)((mean_power + sqrt(mean_power - mean_level^2)) * 65535 + 0.5)
   // demod_2000 / demod_2400 scan kernels: the launch covers strips [strip_begin, strip_end) of the shard (strip_end 0 = nstrips)
   uint32_t        strip_begin, strip_end;
+  // kConvUc8LutR8: rank256[byte] = rank of lut256[byte] among the table's distinct values, rankmag[rank] = that value
+  // (0xFFFF behind the last rank); *inexact is set when a halo magnitude is none of the table's values
+  const uint8_t  *rank256;
+  const uint16_t *rankmag;
+  uint32_t       *inexact;
 };
 
 }  // namespace modes

@@ -184,13 +184,13 @@ __device__ __forceinline__ int table_find (const ErrEntry *tab, int n, uint32_t 
 // ------------------------------------------------------------------------------------------
 // staging: convert samples [a_lo, a_lo + count) into w.tile[0 .. count)
 // ------------------------------------------------------------------------------------------
-template <int CONV> struct RawWords { static constexpr int n = (CONV == kConvUc8Lut || CONV == kConvUc8LutPower) ? 2 : (CONV == kConvUc8Generic || CONV == kConvMagU16) ? 4 : 8; };
+template <int CONV> struct RawWords { static constexpr int n = (CONV == kConvUc8Lut || CONV == kConvUc8LutPower || CONV == kConvUc8LutR8) ? 2 : (CONV == kConvUc8Generic || CONV == kConvMagU16) ? 4 : 8; };
 
 // raw IQ of 8 consecutive samples starting at n0 (a multiple of 8, whole chunk inside the shard)
 template <int CONV>
 __device__ __forceinline__ void load_raw8 (const ScanParams &p, long long n0, uint32_t *d)
 {
-  if (CONV == kConvUc8Lut || CONV == kConvUc8LutPower) {
+  if (CONV == kConvUc8Lut || CONV == kConvUc8LutPower || CONV == kConvUc8LutR8) {
     // as written: output sample i of a block reads input BYTE i of that block (ref: src/convert.c:19,29)
     // block_samples is a power of two (256 KiB / bytes per sample): byte offset = 2 * block start + offset in block
     const uint64_t in_blk = uint64_t (n0) & uint64_t (p.block_samples - 1);
@@ -374,6 +374,96 @@ __device__ __forceinline__ void stage_tile_pos (uint16_t *tile, const uint16_t *
     *reinterpret_cast<uint4 *> (&tile[c]) = pk;
   }
 }
+
+// ------------------------------------------------------------------------------------------
+// kConvUc8LutR8: the tile holds one byte per sample, the rank of its magnitude among the byte table's values
+// (comparisons of ranks are comparisons of magnitudes; rankmag[rank] gives the magnitude back).
+// ------------------------------------------------------------------------------------------
+constexpr int kTileLead8 = 16;
+
+// rank of a magnitude that is not read through the table (the halo in front of the shard): exact only if it is one of
+// the table's values, which a halo formed by this converter always is
+__device__ __forceinline__ uint32_t rank_of_mag (const uint16_t *rankmag, uint32_t m, const ScanParams &p)
+{
+  int lo = 0, hi = 256;
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (rankmag[mid] < m) lo = mid + 1; else hi = mid; }
+  if (lo == 256 || rankmag[lo] != m) { if (p.inexact) atomicOr (p.inexact, 1u); if (lo == 256) lo = 255; }
+  return uint32_t (lo);
+}
+
+__device__ __forceinline__ uint32_t rank_of_sample (const uint8_t *rank, const uint16_t *rankmag, const ScanParams &p, long long n, long long N)
+{
+  if (n < 0) {
+    const uint32_t m = (p.halo && n + (long long) p.ov >= 0) ? p.halo[n + (long long) p.ov] : 0u;
+    return m ? rank_of_mag (rankmag, m, p) : 0u;                   // the table maps byte 0 to magnitude 0: rank 0
+  }
+  if (n >= N) return 0u;
+  const uint64_t blk = uint64_t (n) / p.block_samples, i = uint64_t (n) % p.block_samples;
+  return rank[p.iq[blk * 2 * p.block_samples + i]];
+}
+
+template <int kCount, int kLanes>
+__device__ __forceinline__ void stage_tile_rank8 (uint8_t *tile, const uint8_t *rank, const uint16_t *rankmag, const ScanParams &p, long long s0, int lane)
+{
+  constexpr int kChunks = TileChunks<kCount>::n;
+  constexpr int kIters = (kChunks + kLanes - 1) / kLanes;
+  const long long N = (long long) p.nsamples;
+  const long long a_lo = (s0 >= 0 ? s0 : s0 - 7) / 8 * 8;
+  const int shift = int (s0 - a_lo);                           // 0..7, the same for every wave of a launch
+  if (a_lo >= 0 && a_lo + 8 * kChunks <= N) {
+    uint32_t raw[kIters][2];
+#pragma unroll
+    for (int it = 0; it < kIters; it++) {
+      const int ch = it * kLanes + lane;
+      if (ch < kChunks) load_raw8<kConvUc8LutR8> (p, a_lo + 8 * ch, raw[it]);
+    }
+#pragma unroll
+    for (int it = 0; it < kIters; it++) {
+      const int ch = it * kLanes + lane;
+      if (ch < kChunks) {
+        uint32_t r[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) r[k] = rank[(raw[it][k >> 2] >> (8 * (k & 3))) & 0xFF];
+        const uint32_t w0 = r[0] | (r[1] << 8) | (r[2] << 16) | (r[3] << 24), w1 = r[4] | (r[5] << 8) | (r[6] << 16) | (r[7] << 24);
+        uint8_t *dst = tile + 8 * ch - shift;
+        if (shift == 0) *reinterpret_cast<uint2 *> (dst) = make_uint2 (w0, w1);
+        else if (!(shift & 3)) { reinterpret_cast<uint32_t *> (dst)[0] = w0; reinterpret_cast<uint32_t *> (dst)[1] = w1; }
+        else if (!(shift & 1)) {
+          uint16_t *d16 = reinterpret_cast<uint16_t *> (dst);
+          d16[0] = uint16_t (w0); d16[1] = uint16_t (w0 >> 16); d16[2] = uint16_t (w1); d16[3] = uint16_t (w1 >> 16);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; k++) dst[k] = uint8_t (r[k]);
+        }
+      }
+    }
+    return;
+  }
+  // first / last strips of the shard: per-sample bounds
+  for (int c = lane * 8; c < (kCount + 7) / 8 * 8; c += kLanes * 8) {
+    uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) w0 |= rank_of_sample (rank, rankmag, p, s0 + c + k, N) << (8 * k);
+#pragma unroll
+    for (int k = 0; k < 4; k++) w1 |= rank_of_sample (rank, rankmag, p, s0 + c + 4 + k, N) << (8 * k);
+    *reinterpret_cast<uint2 *> (&tile[c]) = make_uint2 (w0, w1);
+  }
+}
+
+// Reads of the magnitude tile: `mag` for arithmetic, `ord` where only the order of two samples matters.
+template <bool R8> struct TileRef;
+template <> struct TileRef<false> {
+  const uint16_t *p; const uint16_t *rankmag;
+  __device__ __forceinline__ int mag (int i) const { return p[i]; }
+  __device__ __forceinline__ uint32_t ord (int i) const { return p[i]; }
+  __device__ __forceinline__ TileRef at (int o) const { return TileRef { p + o, rankmag }; }
+};
+template <> struct TileRef<true> {
+  const uint8_t *p; const uint16_t *rankmag;
+  __device__ __forceinline__ int mag (int i) const { return rankmag[p[i]]; }
+  __device__ __forceinline__ uint32_t ord (int i) const { return p[i]; }
+  __device__ __forceinline__ TileRef at (int o) const { return TileRef { p + o, rankmag }; }
+};
 
 // ------------------------------------------------------------------------------------------
 // one magnitude of the virtual stream V[x] (x = scan position domain), any converter, slow path

@@ -70,6 +70,8 @@ struct DeviceTables {
   ErrEntry *short_tab = nullptr, *long_tab = nullptr;
   int short_n = 0, long_n = 0;
   uint16_t *lut256 = nullptr;
+  uint8_t *rank256 = nullptr;          // byte -> rank of its table value; rank -> value (see kConvUc8LutR8)
+  uint16_t *rankmag = nullptr;
   uint32_t *bloom_short = nullptr, *bloom_long = nullptr;
   uint16_t *log10_lut = nullptr;
   uint32_t *crc_table = nullptr;
@@ -178,6 +180,7 @@ struct modes_engine {
   std::vector<hipEvent_t> range_events;       // two per range: around its scan
   size_t last_nm = 0;                         // messages of the last run: what the next run's buffers start with
   bool have_last_nm = false;
+  bool no_rank_tile = false;                  // a halo held a magnitude the byte table does not produce: scan with the magnitude tile
   // what the host reads once per accept round, in one copy: 32 totals (u64), 64 `changed` words (one per round), the
   // ICAO cache behind the range's last block
   DevBuf<uint32_t> rb;
@@ -268,6 +271,20 @@ int setup_tables (modes_engine *e)
   build_uc8_byte_lut (lut);
   HIP_TRY (hipMalloc (reinterpret_cast<void **> (&t.lut256), sizeof lut));
   HIP_TRY (hipMemcpy (t.lut256, lut, sizeof lut, hipMemcpyHostToDevice));
+  {
+    // the table's distinct values in ascending order: comparing two samples' ranks is comparing their magnitudes
+    std::vector<uint16_t> vals (lut, lut + 256);
+    std::sort (vals.begin (), vals.end ());
+    vals.erase (std::unique (vals.begin (), vals.end ()), vals.end ());
+    uint8_t rank[256];
+    uint16_t rankmag[256];
+    for (int b = 0; b < 256; b++) rank[b] = uint8_t (std::lower_bound (vals.begin (), vals.end (), lut[b]) - vals.begin ());
+    for (int r = 0; r < 256; r++) rankmag[r] = r < int (vals.size ()) ? vals[r] : uint16_t (0xFFFF);
+    HIP_TRY (hipMalloc (reinterpret_cast<void **> (&t.rank256), sizeof rank));
+    HIP_TRY (hipMemcpy (t.rank256, rank, sizeof rank, hipMemcpyHostToDevice));
+    HIP_TRY (hipMalloc (reinterpret_cast<void **> (&t.rankmag), sizeof rankmag));
+    HIP_TRY (hipMemcpy (t.rankmag, rankmag, sizeof rankmag, hipMemcpyHostToDevice));
+  }
   for (int bits : { kShortBits, kLongBits }) {
     std::vector<ErrEntry> d = e->crc.device_table (bits);
     ErrEntry *p = nullptr;
@@ -546,6 +563,26 @@ int prepare_dc (modes_engine *e, const void *d_iq, size_t nbytes, const uint16_t
   return MODES_OK;
 }
 
+constexpr int kRetryMagnitudeTile = -1000;     // internal: scan again without the rank tile (never leaves run_device_inner)
+constexpr uint32_t kRbInexactWord = 6;         // low word of totals[3] in modes_engine::rb
+
+// What the scan kernel is launched with: for the as-written byte table converter behind the ordered pass on the
+// device, the instance whose LDS tile holds ranks instead of magnitudes (kConvUc8LutR8: half the LDS, 6 instead of 4
+// waves per SIMD with two strips per wave).  The halo is the one input that does not come through the table; a value
+// the table cannot produce is reported through `inexact` and the run is repeated with the magnitude tile.
+ScanParams scan_variant (modes_engine *e, const ScanParams &sp)
+{
+  ScanParams q = sp;
+  const bool off = getenv ("MODES_NO_RANK_TILE") != nullptr;          // tests: compare against the magnitude tile
+  if (e->mode == 2400 && !off && !e->no_rank_tile && !e->cfg.host_replay && !e->cfg.phase_enhance && e->rb.p &&
+      (sp.conv == kConvUc8Lut || sp.conv == kConvUc8LutPower) && sp.block_strips) {
+    q.conv = kConvUc8LutR8;
+    q.rank256 = e->tabs.rank256; q.rankmag = e->tabs.rankmag;
+    q.inexact = e->rb.p + kRbInexactWord;
+  }
+  return q;
+}
+
 // Blocks [blk0, blk0 + nblk) of a shard and their strips: the unit the ordered accept pass works on.
 struct RangeView { uint32_t blk0, nblk, strip0, nstrips; };
 
@@ -655,6 +692,7 @@ int accept_range (modes_engine *e, const ScanParams &sp, uint64_t first_sample, 
   memcpy (e->cache.raw (), e->pin_rb.p + kRbCache, kIcaoSlots * sizeof (uint32_t));
   const unsigned long long *st = reinterpret_cast<const unsigned long long *> (e->pin_rb.p + kRbTotals), *tot = st + 4, *sum = st + 8;
   if (st[2]) return fail (MODES_E_OVERFLOW, "%llu strips overflowed their candidate slots (cap %u)", st[2], e->cap);
+  if (st[3]) return fail (kRetryMagnitudeTile, "the halo holds magnitudes the byte table does not produce");
   e->stats.candidates += st[0];
   const size_t nm = size_t (tot[0]);
   e->stats.demodulated += sum[kStDemodulated]; e->stats.out_of_phase += sum[kStOutOfPhase];
@@ -759,7 +797,7 @@ int scan_and_accept_in_ranges (modes_engine *e, ScanParams &sp, uint64_t first_s
   }
   nranges = uint32_t (rgs.size ());
   auto queue_scan = [&] (uint32_t r) -> hipError_t {
-    ScanParams q = sp;
+    ScanParams q = scan_variant (e, sp);
     q.strip_begin = rgs[r].strip0; q.strip_end = rgs[r].strip0 + rgs[r].nstrips;
     hipError_t he = hipEventRecord (e->range_events[2 * r], stream);
     if (he == hipSuccess) he = e->mode == 2000 ? launch_scan2000 (q, stream) : launch_scan2400 (q, stream);
@@ -772,6 +810,7 @@ int scan_and_accept_in_ranges (modes_engine *e, ScanParams &sp, uint64_t first_s
     ~Drain () { (void) hipStreamSynchronize (e->post_stream); (void) hipStreamSynchronize (e->copy_stream); (void) hipStreamSynchronize (s); }
   } drain = { e, stream };
   e->pin_n = 0;
+  HIP_TRY (hipMemsetAsync (e->rb.p + kRbInexactWord, 0, 2 * sizeof (uint32_t), stream));
   HIP_TRY (queue_scan (0));
   e->scan_launches++;
   for (uint32_t r = 0; r < nranges; r++) {
@@ -868,6 +907,8 @@ void modes_engine_destroy (modes_engine *e)
   if (e->tabs.short_tab) (void) hipFree (e->tabs.short_tab);
   if (e->tabs.long_tab) (void) hipFree (e->tabs.long_tab);
   if (e->tabs.lut256) (void) hipFree (e->tabs.lut256);
+  if (e->tabs.rank256) (void) hipFree (e->tabs.rank256);
+  if (e->tabs.rankmag) (void) hipFree (e->tabs.rankmag);
   if (e->tabs.bloom_short) (void) hipFree (e->tabs.bloom_short);
   if (e->tabs.bloom_long) (void) hipFree (e->tabs.bloom_long);
   if (e->tabs.log10_lut) (void) hipFree (e->tabs.log10_lut);
@@ -930,8 +971,11 @@ static int run_device_inner (modes_engine *e, const void *d_iq, size_t nbytes, u
   }
   for (;;) {
     rc = scan_and_decode (e, sp, first_sample, stream);
-    if (rc != MODES_E_OVERFLOW || e->cap >= cap_max) return rc;
-    e->cap = e->cap * 4 < cap_max ? e->cap * 4 : cap_max;
+    if (rc == kRetryMagnitudeTile) e->no_rank_tile = true;        // for this engine, from now on
+    else {
+      if (rc != MODES_E_OVERFLOW || e->cap >= cap_max) return rc;
+      e->cap = e->cap * 4 < cap_max ? e->cap * 4 : cap_max;
+    }
     e->stats.scan_retries++;
     const uint64_t retries = e->stats.scan_retries;
     if ((rc = e->records.reserve (size_t (sp.nstrips) * e->cap)) != MODES_OK) return rc;
@@ -962,8 +1006,12 @@ static int scan_and_decode (modes_engine *e, ScanParams &sp, uint64_t first_samp
       return rc;
     }
   }
+  if (device_accept) {
+    if ((rc = reserve_accept_buffers (e, sp)) != MODES_OK) return rc;
+    HIP_TRY (hipMemsetAsync (e->rb.p + kRbInexactWord, 0, 2 * sizeof (uint32_t), stream));
+  }
   HIP_TRY (hipEventRecord (e->ev[0], stream));
-  HIP_TRY (e->mode == 2000 ? launch_scan2000 (sp, stream) : launch_scan2400 (sp, stream));
+  HIP_TRY (e->mode == 2000 ? launch_scan2000 (sp, stream) : launch_scan2400 (scan_variant (e, sp), stream));
   e->scan_launches++;
   HIP_TRY (hipEventRecord (e->ev[1], stream));
   HIP_TRY (launch_tail (sp, sp.nsamples, e->tail.p + e->tail_half * ((e->ov + 7u) & ~7u), stream));   // what a following shard needs as d_halo
@@ -1662,7 +1710,12 @@ int modes_engine_time_scan (modes_engine *e, const void *d_iq, size_t nbytes, in
   HIP_TRY (hipEventCreate (&a));
   HIP_TRY (hipEventCreate (&b));
   HIP_TRY (hipEventRecord (a, stream));
-  for (int i = 0; i < reps; i++) HIP_TRY (e->mode == 2000 ? launch_scan2000 (sp, stream) : launch_scan2400 (sp, stream));
+  if (!e->cfg.host_replay && !e->cfg.phase_enhance) {
+    if ((rc = reserve_accept_buffers (e, sp)) != MODES_OK) return rc;
+    HIP_TRY (hipMemsetAsync (e->rb.p + kRbInexactWord, 0, 2 * sizeof (uint32_t), stream));
+  }
+  const ScanParams sv = scan_variant (e, sp);                      // the instance a run would launch
+  for (int i = 0; i < reps; i++) HIP_TRY (e->mode == 2000 ? launch_scan2000 (sp, stream) : launch_scan2400 (sv, stream));
   HIP_TRY (hipEventRecord (b, stream));
   HIP_TRY (hipEventSynchronize (b));
   float ms = 0;

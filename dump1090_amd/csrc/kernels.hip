@@ -26,7 +26,7 @@ namespace modes {
 // waves per SIMD instead of 6, and the kernel is as sensitive to that (4 against 6 waves with single strips: +20 %
 // time) as to the instruction count: the byte-table instance comes out 3.6 % faster, the sc16 one 6 % slower.  So the
 // byte-table converters run with PAIR = 2, the others with single strips.
-template <int CONV> struct ScanPair { static constexpr int n = (CONV == kConvUc8Lut || CONV == kConvUc8LutPower) ? 2 : 1; };
+template <int CONV> struct ScanPair { static constexpr int n = (CONV == kConvUc8Lut || CONV == kConvUc8LutPower || CONV == kConvUc8LutR8) ? 2 : 1; };
 constexpr int kWavesPerBlock = 4;
 constexpr int kQ1Seg = 256;
 constexpr uint32_t kSynSkipped = 0x80000000u;      // stage D1 did not slice the candidate: the reference never looks at it
@@ -62,10 +62,11 @@ __device__ __forceinline__ int phase_score (const int *e, uint32_t &F5)
 }
 
 // one data bit that starts f fifths of a sample after m[0]: > 0 means 1 (ref: src/demod-2400.c:32-55, 339-412)
-__device__ __forceinline__ int slice_at (const uint16_t *m, int f)
+template <typename Ref>
+__device__ __forceinline__ int slice_at (const Ref &m, int f)
 {
   const int i = (f * 0xCCCD) >> 18, ph = f - 5 * i;
-  const int m0 = m[i], m1 = m[i + 1], m2 = m[i + 2], m3 = m[i + 3];
+  const int m0 = m.mag (i), m1 = m.mag (i + 1), m2 = m.mag (i + 2), m3 = m.mag (i + 3);
   const int e0 = m0 - m1, e1 = m1 - m2, e2 = m2 - m3;
   return __mul24 (e0, 5 - ph) + __mul24 (e1, 2 + ph) + __mul24 (e2, ph >> 2);
 }
@@ -86,21 +87,27 @@ template <int CONV, bool PE>
 __global__ __launch_bounds__ (64 * kWavesPerBlock) __attribute__ ((amdgpu_waves_per_eu (SCAN_WAVES, SCAN_WAVES)))
 void scan2400_kernel (const ScanParams p)
 {
-  constexpr bool kLut = CONV == kConvUc8Lut || CONV == kConvUc8LutPower;
+  constexpr bool kR8 = CONV == kConvUc8LutR8;       // the tile holds ranks (one byte per sample), not magnitudes
+  constexpr bool kLut = CONV == kConvUc8Lut || CONV == kConvUc8LutPower || kR8;
   constexpr int kPair = PE ? 1 : ScanPair<CONV>::n;
   constexpr int kSpan = kPair * kStrip;                           // positions one wave scans
   constexpr int kGroupSpan = kWavesPerBlock * kSpan;              // positions one workgroup scans
   constexpr int kStageHalf = kGroupSpan / 2;                      // the tile is staged in two goes (registers)
   constexpr int kTileN = kStageHalf + 8 * TileChunks<kStageHalf + kLook2400>::n;
+  constexpr int kLead = kR8 ? kTileLead8 : kTileLead;
   static_assert (kSpan <= 4096, "queue entries keep a position of the span in 12 bits");
+  static_assert (!(kR8 && PE), "the rank tile is built for the plain scan only");
+  using TileT = typename std::conditional<kR8, uint8_t, uint16_t>::type;
   __shared__ WaveLds<PE, kPair> lds[kWavesPerBlock];
-  __shared__ __attribute__ ((aligned (16))) uint16_t s_tile[kTileLead + kTileN];   // s_tile[kTileLead + x] = V[G0 + x], shared by the four waves
-  __shared__ uint16_t s_lut[kLut ? 256 : 1];        // as-written uc8 table
+  __shared__ __attribute__ ((aligned (16))) TileT s_tile[kLead + kTileN];   // s_tile[kLead + x] = V[G0 + x], shared by the four waves
+  __shared__ uint16_t s_lut[kLut ? 256 : 1];        // as-written uc8 table; rank tile: rank -> magnitude
+  __shared__ uint8_t s_rank[kR8 ? 256 : 1];         // rank tile: byte -> rank
   const int lane = lane_id ();
   const int wv = threadIdx.x >> 6;
   WaveLds<PE, kPair> &w = lds[wv];
   if (kLut) {
-    s_lut[threadIdx.x] = p.lut256[threadIdx.x];
+    s_lut[threadIdx.x] = kR8 ? p.rankmag[threadIdx.x] : p.lut256[threadIdx.x];
+    if (kR8) s_rank[threadIdx.x] = p.rank256[threadIdx.x];
     __syncthreads ();
   }
   const uint32_t strip = p.strip_begin + (blockIdx.x * kWavesPerBlock + wv) * kPair;   // first strip of this wave's span
@@ -116,26 +123,43 @@ void scan2400_kernel (const ScanParams p)
   // ---- stage A: magnitudes V[G0 .. G0 + 4 spans + kLook2400) into LDS, staged by the whole workgroup in two goes ----
   const long long G0 = (long long) p.strip_begin * kStrip + (long long) blockIdx.x * kGroupSpan;
   const long long s0 = G0 - (long long) (CONV == kConvMagU16 ? 0u : p.ov);   // sample index of V[G0] (may be < 0)
-  stage_tile_pos<CONV, kStageHalf, 64 * kWavesPerBlock> (s_tile + kTileLead, s_lut, p, s0, int (threadIdx.x));
-  stage_tile_pos<CONV, kStageHalf + kLook2400, 64 * kWavesPerBlock> (s_tile + kTileLead + kStageHalf, s_lut, p, s0 + kStageHalf, int (threadIdx.x));
+  if constexpr (kR8) {
+    stage_tile_rank8<kStageHalf, 64 * kWavesPerBlock> (s_tile + kLead, s_rank, s_lut, p, s0, int (threadIdx.x));
+    stage_tile_rank8<kStageHalf + kLook2400, 64 * kWavesPerBlock> (s_tile + kLead + kStageHalf, s_rank, s_lut, p, s0 + kStageHalf, int (threadIdx.x));
+  } else {
+    stage_tile_pos<CONV, kStageHalf, 64 * kWavesPerBlock> (s_tile + kLead, s_lut, p, s0, int (threadIdx.x));
+    stage_tile_pos<CONV, kStageHalf + kLook2400, 64 * kWavesPerBlock> (s_tile + kLead + kStageHalf, s_lut, p, s0 + kStageHalf, int (threadIdx.x));
+  }
   __syncthreads ();
   if (strip >= strip_end) return;
   const long long P0 = (long long) strip * kStrip;
-  const uint16_t *V = s_tile + kTileLead + wv * kSpan;
+  const TileRef<kR8> V { s_tile + kLead + wv * kSpan, s_lut };
 
-  if (p.debug_stop == 1) { if (lane == 0) p.counts[strip] = V[lane]; return; }
+  if (p.debug_stop == 1) { if (lane == 0) p.counts[strip] = V.ord (lane); return; }
 
   // ---- stage B, once per strip of the span: lane l owns positions [32 l, 32 l + 32) of the strip: LT/GT bit planes ----
   uint32_t any[kPair], c0[kPair], c1[kPair], c2[kPair];
 #pragma unroll
   for (int h = 0; h < kPair; h++) {
-    const uint16_t *Vh = V + h * kStrip;
+    const TileRef<kR8> Vh = V.at (h * kStrip);
     uint32_t LT = 0, GT = 0;
-    {
-      const uint4 *vw = reinterpret_cast<const uint4 *> (Vh + 32 * lane);
+    if constexpr (kR8) {
+      const uint4 *vw = reinterpret_cast<const uint4 *> (Vh.p + 32 * lane);
+      const uint4 x0 = vw[0], x1 = vw[1];
+      const uint32_t wd[9] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, Vh.ord (32 * lane + 32) };
+#pragma unroll
+      for (int k = 31; k >= 0; k--) {
+        const int a = int ((wd[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+        const int b = int ((wd[(k + 1) >> 2] >> (8 * ((k + 1) & 3))) & 0xFFu);
+        const int d = a - b;
+        LT = alignbit (LT, uint32_t (d), 31);        // shifts in (a < b)
+        GT = alignbit (GT, uint32_t (-d), 31);       // shifts in (a > b)
+      }
+    } else {
+      const uint4 *vw = reinterpret_cast<const uint4 *> (Vh.p + 32 * lane);
       const uint4 x0 = vw[0], x1 = vw[1], x2 = vw[2], x3 = vw[3];
       const uint32_t wd[17] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w,
-                                uint32_t (Vh[32 * lane + 32]) };
+                                Vh.ord (32 * lane + 32) };
 #pragma unroll
       for (int k = 31; k >= 0; k--) {
         const int a = int ((wd[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
@@ -147,7 +171,7 @@ void scan2400_kernel (const ScanParams p)
     }
     uint32_t LTn = dpp_mov<0x130, 0xF, true> (LT), GTn = dpp_mov<0x130, 0xF, true> (GT);   // wave_shl:1 = lane + 1's word
     {   // the word behind the strip, for lane 63
-      const uint32_t a = Vh[kStrip + (lane & 15)], b = Vh[kStrip + (lane & 15) + 1];
+      const uint32_t a = Vh.ord (kStrip + (lane & 15)), b = Vh.ord (kStrip + (lane & 15) + 1);
       const uint32_t l = uint32_t (__ballot (a < b)) & 0xFFFFu, g = uint32_t (__ballot (a > b)) & 0xFFFFu;
       if (lane == 63) { LTn = l; GTn = g; }
     }
@@ -232,10 +256,10 @@ void scan2400_kernel (const ScanParams p)
         const uint32_t qe = w.q1[qi];
         off = qe & 0xFFF;
         const int pat = qe >> 12;
-        const uint16_t *pp = V + off;
+        const TileRef<kR8> pp = V.at (off);
         int s[19];
 #pragma unroll
-        for (int k = 0; k < 19; k++) s[k] = pp[k];
+        for (int k = 0; k < 19; k++) s[k] = pp.mag (k);
         // ref: src/demod-2400.c:233-281; which samples enter high / base_signal / base_noise, by layout index
         const int s39 = s[3] + s[9], s410 = s[4] + s[10];
         const int hsum = s[1] + s[12] + (pat <= 2 ? s39 : 0) + (pat >= 2 ? s410 : 0) + (pat == 4 ? s[2] : 0) + (pat == 0 ? s[11] : 0);
@@ -260,14 +284,14 @@ void scan2400_kernel (const ScanParams p)
       uint32_t ent[PE ? 5 : 1];
       if (qi < nsurv) {
         off = w.q1[qi];
-        const uint16_t *pp = V + off;
+        const TileRef<kR8> pp = V.at (off);
         pass = true;
         {
           int e[14], thr;
           {
             int d[15];
 #pragma unroll
-            for (int k = 0; k < 15; k++) d[k] = pp[19 + k];
+            for (int k = 0; k < 15; k++) d[k] = pp.mag (19 + k);
 #pragma unroll
             for (int k = 0; k < 14; k++) e[k] = d[k] - d[k + 1];
             thr = d[0] + d[1] + d[2] + d[3] + d[4] + d[5];       // threshold of best_phase (ref: :137)
@@ -316,7 +340,7 @@ void scan2400_kernel (const ScanParams p)
           const bool longmsg = slice_bytes_for_df (df) == kLongBytes;   // 14 bytes sliced, else 7 (ref: src/demod-2400.c:416-435)
           const bool longcrc = msg_bits_for_df (df) == kLongBits;       // bits the score's CRC runs over
           if (!PE && coff < c_end) { if (lane == ci) r_syn = kSynSkipped; continue; }
-          const uint16_t *m = V + coff + 19;
+          const TileRef<kR8> m = V.at (coff + 19);
           // syndrome = XOR of the single-bit syndromes of the set bits (the CRC is linear, ref: src/crc.c:56-61)
           const bool bit0 = slice_at (m, t + 12 * bl) > 0;
           u64 m0 = __ballot (bit0), m1 = 0;
@@ -1319,6 +1343,14 @@ hipError_t launch_scan2400 (const ScanParams &p, hipStream_t stream)
     case kConvSc16Generic:    SCAN (kConvSc16Generic); break;
     case kConvSc16Q11Generic: SCAN (kConvSc16Q11Generic); break;
     case kConvMagU16:         SCAN (kConvMagU16); break;
+    case kConvUc8LutR8: {
+      if (p.phase_enhance || !p.rank256 || !p.rankmag) return hipErrorInvalidValue;
+      const uint32_t pair = uint32_t (ScanPair<kConvUc8LutR8>::n);
+      const uint32_t nspans = ((p.strip_end ? p.strip_end : p.nstrips) - p.strip_begin + pair - 1) / pair;
+      const dim3 grid ((nspans + kWavesPerBlock - 1) / kWavesPerBlock);
+      hipLaunchKernelGGL ((scan2400_kernel<kConvUc8LutR8, false>), grid, block, 0, stream, p);
+      break;
+    }
     default: return hipErrorInvalidValue;
   }
 #undef SCAN

@@ -196,3 +196,44 @@ def test_strip_overflow_is_rescanned(monkeypatch):
         assert e.stats()["scan_retries"] >= 1
         assert_same_messages(e.messages(), exp)
         assert e.stats()["valid_preamble"] == est["valid_preamble"]
+
+
+def test_rank_tile_falls_back_on_a_halo_the_table_cannot_produce():
+    """The byte-table scan keeps ranks of the table's values in LDS (kConvUc8LutR8).  The overlap in front of a shard is
+    the one input that does not come through the table: with a halo formed by the converter the rank tile is exact; a
+    halo holding any other magnitude makes the engine scan again with the magnitude tile -- same result either way."""
+    import os
+    import torch
+    n = 131072 * 5
+    iq, _ = synth.capture_lut_image(n, 2.4e6, seed=61, frames_per_sec=3000, min_amp_db=-22, ap_fraction=0.3, n_icao=6)
+    d = torch.from_numpy(iq).to("cuda:0")
+    first = 131072 * 2
+
+    def shard_with(halo, plain):
+        if plain:
+            os.environ["MODES_NO_RANK_TILE"] = "1"
+        try:
+            e = da.Engine(2400000, da.INPUT_UC8)
+            e.run_device(d.data_ptr() + 2 * first, 2 * (n - first), first_sample=first, halo_ptr=halo.data_ptr())
+            torch.cuda.synchronize()
+            return e
+        finally:
+            os.environ.pop("MODES_NO_RANK_TILE", None)
+    lead = da.Engine(2400000, da.INPUT_UC8)
+    lead.run_device(d.data_ptr(), 2 * first)
+    ov = 326
+    good = torch.empty(ov + 8, dtype=torch.int16, device="cuda:0")
+    lead.halo_at(d.data_ptr(), 2 * n, first, good.data_ptr())
+    torch.cuda.synchronize()
+    a, b = shard_with(good, False), shard_with(good, True)
+    assert a.stats()["scan_retries"] == 0 and len(a.messages()) > 200
+    assert a.messages().tobytes() == b.messages().tobytes()
+    for k in ("valid_preamble", "candidates", "demodulated"):
+        assert a.stats()[k] == b.stats()[k], k
+    odd = good.clone()
+    odd[ov - 40:ov] += 7                                         # 360 * k + 7: no byte maps to that
+    a, b = shard_with(odd, False), shard_with(odd, True)
+    assert a.stats()["scan_retries"] == 1 and b.stats()["scan_retries"] == 0
+    assert a.messages().tobytes() == b.messages().tobytes()
+    for k in ("valid_preamble", "candidates", "demodulated"):
+        assert a.stats()[k] == b.stats()[k], k
