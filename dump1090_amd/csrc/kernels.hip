@@ -118,7 +118,6 @@ void scan2400_kernel (const ScanParams p)
   // stage D maps lane -> message bit (lane ^ 7) (+ 64 in the second round): a ballot then holds the message bytes as they
   // lie in memory.  Single-bit syndromes of those bits for 112-bit and 56-bit CRCs (ref: src/crc.c:35,56-61)
   const int bl = lane ^ 7;
-  const uint32_t sbL0 = c_single_bit[bl], sbL1 = bl < 48 ? c_single_bit[64 + bl] : 0u, sbS = bl < 56 ? c_single_bit[56 + bl] : 0u;
 
   // ---- stage A: magnitudes V[G0 .. G0 + 4 spans + kLook2400) into LDS, staged by the whole workgroup in two goes ----
   const long long G0 = (long long) p.strip_begin * kStrip + (long long) blockIdx.x * kGroupSpan;
@@ -333,6 +332,8 @@ void scan2400_kernel (const ScanParams p)
 
       for (int b2 = 0; b2 < n2 && !overflow; b2 += 64) {
         const int nq = min (n2 - b2, 64);
+        // (fetched here, not at the top of the kernel: three registers less to carry through stages A to C)
+        const uint32_t sbL0 = c_single_bit[bl], sbL1 = bl < 48 ? c_single_bit[64 + bl] : 0u, sbS = bl < 56 ? c_single_bit[56 + bl] : 0u;
         // ---- stage D1: 56/112-bit slicing + CRC syndrome, one candidate at a time, one lane per message bit ----
         for (int ci = 0; ci < nq; ci++) {
           const uint32_t qe = uint32_t (__builtin_amdgcn_readfirstlane (int (w.q2[b2 + ci])));
