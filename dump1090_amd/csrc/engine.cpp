@@ -190,7 +190,6 @@ struct modes_engine {
   PinBuf<D8Window> pin_wins;
   PinBuf<Record> pin_recs;
   PinBuf<uint32_t> pin_bits;                  // announce bitmap as the run starts with it
-  PinBuf<uint32_t> pin_counts;                // per-chunk window / record counts
   PinBuf<uint64_t> pin_rpos;                  // 8 MS/s: positions and lengths of the messages to measure, staged for the device
   PinBuf<uint32_t> pin_rlen;
   PinBuf<uint64_t> pin_sums, pin_tot;         // pin_tot: four totals per range of chunks, written by the device
@@ -784,11 +783,9 @@ int scan_and_accept_in_ranges (modes_engine *e, ScanParams &sp, uint64_t first_s
   std::vector<RangeView> rgs;
   // Ranges shrink towards the end (weights R, R-1, .. 1): what is left to do when the last scan ends -- the last
   // range's pass, emit and read-back -- is what the overlap cannot hide.
-  const bool taper = !getenv ("MODES_RANGES_EVEN");
-  const uint64_t wsum = taper ? uint64_t (nranges) * (nranges + 1) / 2 : nranges;
+  const uint64_t wsum = uint64_t (nranges) * (nranges + 1) / 2;
   auto cut = [&] (uint32_t r) -> uint32_t {       // first block of range r
-    const uint64_t w = taper ? uint64_t (r) * (2 * nranges - r + 1) / 2 : r;
-    return uint32_t (uint64_t (nblocks) * w / wsum);
+    return uint32_t (uint64_t (nblocks) * (uint64_t (r) * (2 * nranges - r + 1) / 2) / wsum);
   };
   for (uint32_t r = 0; r < nranges; r++) {
     const uint32_t b0 = cut (r), b1 = r + 1 == nranges ? nblocks : cut (r + 1);
@@ -901,7 +898,7 @@ void modes_engine_destroy (modes_engine *e)
   if (e->copy_stream) (void) hipStreamDestroy (e->copy_stream);
   for (hipEvent_t ev : e->emit_events) if (ev) (void) hipEventDestroy (ev);
   for (hipEvent_t ev : e->range_events) if (ev) (void) hipEventDestroy (ev);
-  e->pin_wins.release (); e->pin_recs.release (); e->pin_bits.release (); e->pin_counts.release ();
+  e->pin_wins.release (); e->pin_recs.release (); e->pin_bits.release ();
   for (hipEvent_t ev : e->d8_events) if (ev) (void) hipEventDestroy (ev);
   for (hipEvent_t ev : e->d8_gathered) if (ev) (void) hipEventDestroy (ev);
   if (e->tabs.short_tab) (void) hipFree (e->tabs.short_tab);

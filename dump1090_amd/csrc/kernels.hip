@@ -25,7 +25,8 @@ namespace modes {
 // instructions per strip by 18 % (uc8 byte table) / 10 % (sc16), but its 8 KB of magnitudes per wave leave room for 4
 // waves per SIMD instead of 6, and the kernel is as sensitive to that (4 against 6 waves with single strips: +20 %
 // time) as to the instruction count: the byte-table instance comes out 3.6 % faster, the sc16 one 6 % slower.  So the
-// byte-table converters run with PAIR = 2, the others with single strips.
+// byte-table converters run with PAIR = 2, the others with single strips.  kConvUc8LutR8 -- the byte-table instance whose
+// tile holds ranks, one byte per sample (device_common.h) -- has the pair AND the 6 waves: a further 8 % faster.
 template <int CONV> struct ScanPair { static constexpr int n = (CONV == kConvUc8Lut || CONV == kConvUc8LutPower || CONV == kConvUc8LutR8) ? 2 : 1; };
 constexpr int kWavesPerBlock = 4;
 constexpr int kQ1Seg = 256;
