@@ -7,113 +7,6 @@ namespace modes {
 
 void IcaoCache::clear () { memset (slot_, 0, sizeof slot_); }
 
-uint32_t IcaoCache::hash (uint32_t a)
-{
-  a = ((a >> 16) ^ a) * 0x45D9F3Bu;
-  a = ((a >> 16) ^ a) * 0x45D9F3Bu;
-  a = (a >> 16) ^ a;
-  return a & (kIcaoSlots - 1);
-}
-
-static inline uint32_t aa_field (const uint8_t *msg) { return (uint32_t (msg[1]) << 16) | (uint32_t (msg[2]) << 8) | msg[3]; }
-
-// AA as it would read after the table's repair (ref: src/dump1090.c:3225-3241): only flips that land in bits 8..31
-static inline uint32_t aa_after_repair (const Record &r)
-{
-  uint32_t a = aa_field (r.msg);
-  const int8_t b[2] = { r.bit0, r.bit1 };
-  for (int i = 0; i < r.nerr; i++)
-    if (b[i] >= 8 && b[i] <= 31) a ^= 1u << (31 - b[i]);
-  return a;
-}
-
-int score_record (const Record &r, const IcaoCache &cache)
-{
-  switch (r.cls) {
-    case kClsAP:  return cache.test (r.crc) ? 1000 : -1;
-    case kClsAP2: return cache.test (r.crc) ? 1000 : -2;
-    case kClsDF11: {
-      const bool known = cache.test (aa_after_repair (r));
-      if ((r.crc & 0x7F) == 0) return (known ? 1600 : 750) / (r.nerr + 1);
-      return known ? 1000 / (r.nerr + 1) : -1;
-    }
-    default:
-      return (cache.test (aa_after_repair (r)) ? 1800 : 1400) / (r.nerr + 1);
-  }
-}
-
-// Which extended squitters carry a non-ICAO address (the only output of decode_extended_squitter
-// that reaches mm->addr; ref: src/dump1090.c:1918-1963, 1990, 2097, 2130, 2220, 2239).
-static uint32_t non_icao_flag (const uint8_t *msg, int df)
-{
-  bool look_for_imf = false;
-  if (df == 18) {
-    const int cf = msg[0] & 7;
-    if (cf == 1 || cf == 5) return kNonIcao;
-    if (cf == 3) return (msg[4] & 0x80) ? kNonIcao : 0;
-    if (cf == 4 || cf == 7) return kNonIcao;
-    look_for_imf = (cf == 2 || cf == 6);
-  }
-  if (!look_for_imf) return 0;
-  const int type = msg[4] >> 3;
-  bool imf = false;
-  if (type == 19) imf = msg[5] & 0x80;
-  else if (type >= 5 && type <= 8) imf = msg[6] & 0x08;
-  else if (type == 0 || (type >= 9 && type <= 18) || (type >= 20 && type <= 22)) imf = msg[4] & 0x01;
-  else if (type == 28) imf = (msg[4] & 7) == 1 && (msg[10] & 0x01);
-  else if (type == 31) imf = msg[10] & 0x01;
-  return imf ? kNonIcao : 0;
-}
-
-static inline void flip (uint8_t *msg, int bit) { msg[bit >> 3] ^= uint8_t (0x80u >> (bit & 7)); }
-
-int accept_record (const Record &r, IcaoCache &cache, modes_message *out)
-{
-  uint8_t *msg = out->msg;
-  memcpy (msg, r.msg, kLongBytes);
-  out->msg_type = r.df;
-  out->msg_bits = uint8_t (len_by_type (r.df));
-  out->crc = r.crc;
-  out->error_bits = 0;
-  out->addr = 0;
-  out->sig_level = 0.0;
-
-  bool clean_announcer = false;
-  switch (r.cls) {
-    case kClsAP:
-    case kClsAP2:
-      if (!cache.test (r.crc)) return -1;
-      out->addr = r.crc;
-      if (r.df >= 24) out->msg_type = 24;
-      return 0;
-    case kClsDF11:
-      if (r.crc & 0xFFFF80u) {
-        out->error_bits = uint8_t (r.nerr);
-        if (r.nerr >= 1) flip (msg, r.bit0);
-        if (!cache.test (aa_field (msg))) return -1;
-      }
-      out->addr = aa_field (msg);
-      clean_announcer = out->error_bits == 0 && (r.crc & 0x7F) == 0;
-      break;
-    default: {
-      if (r.crc != 0) {
-        const uint32_t before = aa_field (msg);
-        out->error_bits = uint8_t (r.nerr);
-        if (r.nerr >= 1) flip (msg, r.bit0);
-        if (r.nerr >= 2) flip (msg, r.bit1);
-        const uint32_t after = aa_field (msg);
-        if (r.nerr == 2 && !cache.test (after)) return -1;
-        if (r.nerr == 1 && before != after && !cache.test (after)) return -1;
-      }
-      out->addr = aa_field (msg) | non_icao_flag (msg, r.df);
-      clean_announcer = out->error_bits == 0;
-      break;
-    }
-  }
-  if (clean_announcer) cache.add (out->addr);
-  return 0;
-}
-
 void accept_pass_2400 (const Record *rec, const uint64_t *pos, size_t n, uint32_t B, uint64_t first_sample,
                        uint32_t sample_rate, IcaoCache &cache, AcceptStats &st,
                        std::vector<modes_message> &out, std::vector<uint64_t> &out_pos,
@@ -257,7 +150,9 @@ void accept_pass_2000 (const Record *rec, const uint64_t *pos, size_t n, uint32_
 void accept_pass_8000 (const D8Window *win, size_t nwin, const Record *rec, uint32_t B, int bshift, uint64_t T, uint32_t ov,
                        uint64_t first_sample, uint32_t sample_rate, const Pass8000Hooks &hooks, Pass8000Stats &st)
 {
-  accept_pass_8000_with (win, nwin, rec, B, bshift, T, ov, first_sample, sample_rate, hooks.score, hooks.decode, hooks.emit, st);
+  modes_message mm;
+  accept_pass_8000_with (win, nwin, rec, B, bshift, T, ov, first_sample, sample_rate, hooks.score, hooks.decode, hooks.emit,
+                         [&] { return &mm; }, st);
 }
 
 void accept_pass_2400ac (const Record *rec, const uint64_t *pos, size_t n, uint32_t B, uint64_t first_sample,

@@ -33,14 +33,120 @@ struct AcceptStats {
            skipped_preambles = 0;   // valid preambles the reference never saw: inside a skipped-over message
 };
 
-// score of one record against the cache (ref: src/dump1090.c:3279-3365)
-int score_record (const Record &r, const IcaoCache &cache);
-// accept rules + repair (ref: src/dump1090.c:2372-2578, 2586-2587, 2676-2687); fills msg/addr/... of `out`.
-// Returns 0, -1 (unknown ICAO), -2 (CRC).  Adds to the cache exactly where the reference does.
-int accept_record (const Record &r, IcaoCache &cache, modes_message *out);
-
 // ref: src/dump1090.c:1427-1432
 inline int len_by_type (int df) { return (df == 16 || df == 17 || df == 19 || df == 20 || df == 21) ? kLongBits : kShortBits; }
+
+// score_record: score of one record against the cache (ref: src/dump1090.c:3279-3365).
+// accept_record: accept rules + repair (ref: src/dump1090.c:2372-2578, 2586-2587, 2676-2687); fills msg/addr/... of `out`;
+// returns 0, -1 (unknown ICAO), -2 (CRC); adds to the cache exactly where the reference does.
+// Defined here: the ordered walks call them once or twice per candidate.
+inline uint32_t IcaoCache::hash (uint32_t a)
+{
+  a = ((a >> 16) ^ a) * 0x45D9F3Bu;
+  a = ((a >> 16) ^ a) * 0x45D9F3Bu;
+  a = (a >> 16) ^ a;
+  return a & (kIcaoSlots - 1);
+}
+
+inline uint32_t aa_field (const uint8_t *msg) { return (uint32_t (msg[1]) << 16) | (uint32_t (msg[2]) << 8) | msg[3]; }
+
+// AA as it would read after the table's repair (ref: src/dump1090.c:3225-3241): only flips that land in bits 8..31
+inline uint32_t aa_after_repair (const Record &r)
+{
+  uint32_t a = aa_field (r.msg);
+  const int8_t b[2] = { r.bit0, r.bit1 };
+  for (int i = 0; i < r.nerr; i++)
+    if (b[i] >= 8 && b[i] <= 31) a ^= 1u << (31 - b[i]);
+  return a;
+}
+
+inline int score_record (const Record &r, const IcaoCache &cache)
+{
+  switch (r.cls) {
+    case kClsAP:  return cache.test (r.crc) ? 1000 : -1;
+    case kClsAP2: return cache.test (r.crc) ? 1000 : -2;
+    case kClsDF11: {
+      const bool known = cache.test (aa_after_repair (r));
+      if ((r.crc & 0x7F) == 0) return (known ? 1600 : 750) / (r.nerr + 1);
+      return known ? 1000 / (r.nerr + 1) : -1;
+    }
+    default:
+      return (cache.test (aa_after_repair (r)) ? 1800 : 1400) / (r.nerr + 1);
+  }
+}
+
+// Which extended squitters carry a non-ICAO address (the only output of decode_extended_squitter
+// that reaches mm->addr; ref: src/dump1090.c:1918-1963, 1990, 2097, 2130, 2220, 2239).
+inline uint32_t non_icao_flag (const uint8_t *msg, int df)
+{
+  bool look_for_imf = false;
+  if (df == 18) {
+    const int cf = msg[0] & 7;
+    if (cf == 1 || cf == 5) return kNonIcao;
+    if (cf == 3) return (msg[4] & 0x80) ? kNonIcao : 0;
+    if (cf == 4 || cf == 7) return kNonIcao;
+    look_for_imf = (cf == 2 || cf == 6);
+  }
+  if (!look_for_imf) return 0;
+  const int type = msg[4] >> 3;
+  bool imf = false;
+  if (type == 19) imf = msg[5] & 0x80;
+  else if (type >= 5 && type <= 8) imf = msg[6] & 0x08;
+  else if (type == 0 || (type >= 9 && type <= 18) || (type >= 20 && type <= 22)) imf = msg[4] & 0x01;
+  else if (type == 28) imf = (msg[4] & 7) == 1 && (msg[10] & 0x01);
+  else if (type == 31) imf = msg[10] & 0x01;
+  return imf ? kNonIcao : 0;
+}
+
+inline void flip (uint8_t *msg, int bit) { msg[bit >> 3] ^= uint8_t (0x80u >> (bit & 7)); }
+
+inline int accept_record (const Record &r, IcaoCache &cache, modes_message *out)
+{
+  uint8_t *msg = out->msg;
+  memcpy (msg, r.msg, kLongBytes);
+  out->msg_type = r.df;
+  out->msg_bits = uint8_t (len_by_type (r.df));
+  out->crc = r.crc;
+  out->error_bits = 0;
+  out->addr = 0;
+  out->sig_level = 0.0;
+
+  bool clean_announcer = false;
+  switch (r.cls) {
+    case kClsAP:
+    case kClsAP2:
+      if (!cache.test (r.crc)) return -1;
+      out->addr = r.crc;
+      if (r.df >= 24) out->msg_type = 24;
+      return 0;
+    case kClsDF11:
+      if (r.crc & 0xFFFF80u) {
+        out->error_bits = uint8_t (r.nerr);
+        if (r.nerr >= 1) flip (msg, r.bit0);
+        if (!cache.test (aa_field (msg))) return -1;
+      }
+      out->addr = aa_field (msg);
+      clean_announcer = out->error_bits == 0 && (r.crc & 0x7F) == 0;
+      break;
+    default: {
+      if (r.crc != 0) {
+        const uint32_t before = aa_field (msg);
+        out->error_bits = uint8_t (r.nerr);
+        if (r.nerr >= 1) flip (msg, r.bit0);
+        if (r.nerr >= 2) flip (msg, r.bit1);
+        const uint32_t after = aa_field (msg);
+        if (r.nerr == 2 && !cache.test (after)) return -1;
+        if (r.nerr == 1 && before != after && !cache.test (after)) return -1;
+      }
+      out->addr = aa_field (msg) | non_icao_flag (msg, r.df);
+      clean_announcer = out->error_bits == 0;
+      break;
+    }
+  }
+  if (clean_announcer) cache.add (out->addr);
+  return 0;
+}
+
 
 // The per-block ordered walk of demod_2400 (ref: src/demod-2400.c:200-520) over records sorted by
 // stream position.  `pos[i]` is the scan position of records[i] inside the shard.
@@ -93,10 +199,14 @@ void accept_pass_8000 (const D8Window *win, size_t nwin, const Record *rec, uint
 
 // The same walk with the three hooks as plain callables (the bulk engine inlines its own rules here; the function above
 // wraps the bound host callbacks of the drop-in entry point).
-template <class Score, class Decode, class Emit>
+// `slot ()` says where the next message is to be built; `emit` is handed that place back (a caller that collects the
+// messages in an array moves on by one there, or leaves the place to the next message).
+template <class Score, class Decode, class Emit, class Slot>
 inline void accept_pass_8000_with (const D8Window *win, size_t nwin, const Record *rec, uint32_t B, int bshift, uint64_t T, uint32_t ov,
-                                   uint64_t first_sample, uint32_t sample_rate, Score &&score, Decode &&decode, Emit &&emit, Pass8000Stats &st)
+                                   uint64_t first_sample, uint32_t sample_rate, Score &&score, Decode &&decode, Emit &&emit, Slot &&slot,
+                                   Pass8000Stats &st_out)
 {
+  Pass8000Stats st = st_out;                                        // counted in registers, handed back at the end
   uint64_t ts_blk = ~0ull, block_ts = 0;                           // block_ts of the block seen last (it changes every 64 K samples)
   for (size_t wi = 0; wi < nwin; wi++) {
     const D8Window &w = win[wi];
@@ -121,7 +231,7 @@ inline void accept_pass_8000_with (const D8Window *win, size_t nwin, const Recor
       ts_blk = blkc;
     }
     const uint64_t ts = block_ts + uint64_t (int64_t ((position - kD8LookAhead - slen - int (ov)) * 12 / 8));   // ref: :421-422
-    modes_message mm;
+    modes_message &mm = *slot ();
     memset (&mm, 0, sizeof mm);
     const int rc = decode (r, ts, &mm);
     if (rc < 0) { st.CRC_bad++; if (rc == -1) st.rejected_unknown++; continue; }
@@ -135,6 +245,7 @@ inline void accept_pass_8000_with (const D8Window *win, size_t nwin, const Recor
     if (!(m_start >= 0 && uint64_t (m_start + slen) <= mlen_c)) m_start = -1;
     emit (mm, r, blkc, m_start, slen);
   }
+  st_out = st;
 }
 
 }  // namespace modes

@@ -242,7 +242,10 @@ __device__ __forceinline__ uint4 convert_raw8 (const uint16_t *lut, const uint32
 
 // kTileCount (a multiple of 8) samples starting at sample index a_lo (a multiple of 8; may be negative or run
 // past the end: those read the halo / zeros).  `lut` = the as-written uc8 table in LDS.
-template <int CONV, int kTileCount>
+// PAD: 16 bytes of padding behind every 256 samples of the tile (sample i sits at i + 8 * (i >> 8)): lanes that read
+// the tile 256 samples apart -- the eight 32-step segments of the demod_8000 trigger kernel -- then hit different banks.
+__device__ __forceinline__ constexpr int tile_pad (int i) { return i + 8 * (i >> 8); }
+template <int CONV, int kTileCount, bool PAD = false>
 __device__ __forceinline__ void stage_tile (uint16_t *tile, const uint16_t *lut, const ScanParams &p, long long a_lo, int lane)
 {
   constexpr int kTileChunks = kTileCount / 8;
@@ -260,7 +263,7 @@ __device__ __forceinline__ void stage_tile (uint16_t *tile, const uint16_t *lut,
 #pragma unroll
     for (int it = 0; it < kTileIters; it++) {
       const int ch = it * 64 + lane;
-      if (ch < kTileChunks) *reinterpret_cast<uint4 *> (&tile[8 * ch]) = convert_raw8<CONV> (lut, raw[it]);
+      if (ch < kTileChunks) *reinterpret_cast<uint4 *> (&tile[PAD ? tile_pad (8 * ch) : 8 * ch]) = convert_raw8<CONV> (lut, raw[it]);
     }
     return;
   }
@@ -301,7 +304,7 @@ __device__ __forceinline__ void stage_tile (uint16_t *tile, const uint16_t *lut,
       pk.x = out[0] | (uint32_t (out[1]) << 16); pk.y = out[2] | (uint32_t (out[3]) << 16);
       pk.z = out[4] | (uint32_t (out[5]) << 16); pk.w = out[6] | (uint32_t (out[7]) << 16);
     }
-    *reinterpret_cast<uint4 *> (&tile[c]) = pk;
+    *reinterpret_cast<uint4 *> (&tile[PAD ? tile_pad (c) : c]) = pk;
   }
 }
 

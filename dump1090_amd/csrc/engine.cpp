@@ -192,12 +192,14 @@ struct modes_engine {
   PinBuf<uint32_t> pin_bits;                  // announce bitmap as the run starts with it
   PinBuf<uint64_t> pin_rpos;                  // 8 MS/s: positions and lengths of the messages to measure, staged for the device
   PinBuf<uint32_t> pin_rlen;
+  std::vector<uint32_t> d8_lvl_msg;           // 8 MS/s: which message each measured level belongs to
   PinBuf<uint64_t> pin_sums, pin_tot;         // pin_tot: four totals per range of chunks, written by the device
   DevBuf<uint64_t> d8_tot;
   PinBuf<D8Window> pin_wins2;                 // a range that outgrew its share of pin_wins / pin_recs
   PinBuf<Record> pin_recs2;
   uint64_t d8_last_chunks = 0, d8_last_nwin = 0, d8_last_nrec = 0, d8_last_msgs = 0;   // the last run: sizes the next run's arrays                  // 8 MS/s: signal sums of the accepted messages, range by range
   std::vector<hipEvent_t> d8_gathered;        // one per range of chunks: its packed windows / records are in pinned memory
+  hipEvent_t d8_chain_done = nullptr, d8_edges_done = nullptr;   // the window list stands / the windows at block edges are done
   std::vector<hipEvent_t> d8_events;          // three per range of chunks: windows begin / end, counts (then records) on the host
   unsigned long long *d_stats = nullptr;
   uint32_t cap = 0;
@@ -901,6 +903,8 @@ void modes_engine_destroy (modes_engine *e)
   e->pin_wins.release (); e->pin_recs.release (); e->pin_bits.release ();
   for (hipEvent_t ev : e->d8_events) if (ev) (void) hipEventDestroy (ev);
   for (hipEvent_t ev : e->d8_gathered) if (ev) (void) hipEventDestroy (ev);
+  if (e->d8_chain_done) (void) hipEventDestroy (e->d8_chain_done);
+  if (e->d8_edges_done) (void) hipEventDestroy (e->d8_edges_done);
   if (e->tabs.short_tab) (void) hipFree (e->tabs.short_tab);
   if (e->tabs.long_tab) (void) hipFree (e->tabs.long_tab);
   if (e->tabs.lut256) (void) hipFree (e->tabs.lut256);
@@ -1186,6 +1190,9 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
 {
   if (first_sample % e->block_samples && nbytes / bytes_per_sample (e->cfg.input_format) > e->block_samples)
     return fail (MODES_E_ARG, "first_sample must be a multiple of the block length");
+  const auto t_entry = std::chrono::steady_clock::now ();
+  auto since_entry = [&] { return std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - t_entry).count (); };
+  const bool timing = getenv ("MODES_TIMING") != nullptr;
   HIP_TRY (hipSetDevice (e->cfg.device));
   e->messages.clear ();
   e->in_pinned = false; e->pin_n = 0;
@@ -1288,6 +1295,7 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
     HIP_TRY (launch_d8_last_amb (q.amb, nwords, d_limit, stream));
     HIP_TRY (hipMemcpyAsync (&limit, d_limit, sizeof limit, hipMemcpyDeviceToHost, stream));
     HIP_TRY (hipStreamSynchronize (stream));
+    if (timing) fprintf (stderr, "  %.3f ms: trigger planes done\n", since_entry ());
     if (limit && have_in && !e->d8_in.acc_valid)
       return fail (MODES_E_ARG, "demod_8000: this shard holds steps whose trigger depends on the running average (near-silent input): "
                                 "the state handed over must carry acc (modes_engine_get_d8_state with want_acc)");
@@ -1371,15 +1379,16 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   // the messages it accepted on a second stream.  A record of range r can only be accepted through an address announced
   // in ranges <= r (or cached at the start), and count(r) runs behind windows(r), so the address filter sees all it needs.
   // The pinned arrays are sized from the last run (or a default per chunk); a range that does not fit is gathered again
-  // into arrays of the right size.  Ranges shrink a little towards the end: what is left when the last window kernel
-  // ends is the walk over the last range.
-  uint32_t nranges = nchunks >= 256 ? 6u : nchunks >= 16 ? 4u : 1u;
+  // into arrays of the right size.
+  uint32_t nranges = nchunks >= 256 ? 8u : nchunks >= 16 ? 4u : 1u;
   if (const char *ev = getenv ("MODES_RANGES")) { const int v = atoi (ev); if (v >= 1 && v <= 64) nranges = uint32_t (v) < nchunks ? uint32_t (v) : nchunks; }
   if (e->d8_events.size () < 3 * size_t (nranges)) {
     const size_t have = e->d8_events.size ();
     e->d8_events.resize (3 * size_t (nranges), nullptr);
     for (size_t i = have; i < e->d8_events.size (); i++) HIP_TRY (hipEventCreate (&e->d8_events[i]));
   }
+  if (!e->d8_chain_done) HIP_TRY (hipEventCreateWithFlags (&e->d8_chain_done, hipEventDisableTiming));
+  if (!e->d8_edges_done) HIP_TRY (hipEventCreateWithFlags (&e->d8_edges_done, hipEventDisableTiming));
   while (e->d8_gathered.size () < nranges) {
     hipEvent_t ev;
     HIP_TRY (hipEventCreateWithFlags (&ev, hipEventDisableTiming));
@@ -1391,9 +1400,9 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   struct Drain { hipStream_t a, b, c; ~Drain () { (void) hipStreamSynchronize (a); (void) hipStreamSynchronize (b); (void) hipStreamSynchronize (c); } } drain = { side, lvl, stream };
   std::vector<uint32_t> lo (nranges + 1);
   {
-    // each range 0.8 of the one before: the walk over range r (3/4 of the device's time per chunk) ends before the
-    // device is through with range r + 1
-    const double ratio = 0.8;
+    // equal ranges: the walk over a range takes the host about as long as the range takes the device, so the host
+    // follows one range behind and what is left when the last window kernel ends is the walk over one range
+    const double ratio = 1.0;
     double wsum = 0, run = 0, w = 1.0;
     for (uint32_t r = 0; r < nranges; r++, w *= ratio) wsum += w;
     w = 1.0;
@@ -1411,12 +1420,28 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   if ((rc = e->pin_recs.reserve (size_t (nchunks) * br + 1)) != MODES_OK) return rc;
   if ((rc = e->d8_tot.reserve (4 * size_t (nranges))) != MODES_OK) return rc;
   if ((rc = e->pin_tot.reserve (4 * size_t (nranges))) != MODES_OK) return rc;
+  // the few windows at block edges are slow ones: all of them in one launch, not a tail behind every range
+  // (a few waves that wait a lot: on the second stream, beside the first range's windows)
+  // (a few waves that wait a lot: the first range's in front of its other windows, the rest on the second stream
+  // beside them)
+  if (!same_windows) {
+    q.chunk0 = 0;
+    HIP_TRY (launch_d8_windows (q, lo[1], stream, 2));
+    if (nranges > 1) {
+      HIP_TRY (hipEventRecord (e->d8_chain_done, stream));
+      HIP_TRY (hipStreamWaitEvent (lvl, e->d8_chain_done, 0));     // (the stream of the signal levels: idle until the first walk is over)
+      q.chunk0 = lo[1];
+      HIP_TRY (launch_d8_windows (q, nchunks - lo[1], lvl, 2));
+      HIP_TRY (hipEventRecord (e->d8_edges_done, lvl));
+    }
+  }
   for (uint32_t r = 0; r < nranges; r++) {
     const uint32_t c0 = lo[r], n = lo[r + 1] - c0;
     q.chunk0 = c0;
     HIP_TRY (hipEventRecord (e->d8_events[3 * r], stream));
-    if (!same_windows) HIP_TRY (launch_d8_windows (q, n, stream));
+    if (!same_windows) HIP_TRY (launch_d8_windows (q, n, stream, 1));
     HIP_TRY (hipEventRecord (e->d8_events[3 * r + 1], stream));
+    if (r == 1 && !same_windows) HIP_TRY (hipStreamWaitEvent (stream, e->d8_edges_done, 0));
     HIP_TRY (launch_d8_count (q, n, e->d8_chunk_rec.p, stream));
     HIP_TRY (launch_d8_offsets (e->d8_chunk_rec.p, e->d8_win_count.p, nchunks, c0, n, e->d8_off.p, e->d8_off.p + nchunks + 1,
                                 uint64_t (n) * bw, uint64_t (n) * br, e->d8_tot.p + 4 * r, e->pin_tot.p + 4 * r, stream));
@@ -1428,9 +1453,31 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
     HIP_TRY (hipEventRecord (e->d8_gathered[r], side));
   }
   Pass8000Stats ps;
-  std::vector<uint64_t> rpos; std::vector<uint32_t> rlen;
-  struct LevelOf { size_t msg, sum; uint32_t len; };
-  std::vector<LevelOf> level_of;                        // message, index of its sum in pin_sums, samples summed
+  if (timing) fprintf (stderr, "  %.3f ms: everything queued\n", since_entry ());
+  // the messages whose signal level is measured, over all ranges: pin_rpos / pin_rlen (position, samples summed),
+  // lvl_msg (index in e->messages), pin_sums (what the device found); range r's part starts where range r - 1's ended
+  std::vector<uint32_t> &lvl_msg = e->d8_lvl_msg;
+  auto level_room = [&] (size_t n) -> int {
+    if (n <= e->pin_rpos.cap && n <= e->pin_rlen.cap && n <= e->pin_sums.cap && n <= e->rssi_pos.cap && n <= e->rssi_len.cap && n <= e->rssi_sum.cap) return MODES_OK;
+    // (first run, or more messages than the run before) nothing of an earlier range may be in flight in what grows
+    hipError_t he = hipStreamSynchronize (lvl);
+    if (he != hipSuccess) return fail (MODES_E_HIP, "hipStreamSynchronize: %s", hipGetErrorString (he));
+    const size_t want = 2 * n;
+    int rc2;
+    PinBuf<uint64_t> sums; PinBuf<uint32_t> lens; PinBuf<uint64_t> poss;
+    if ((rc2 = sums.reserve (want)) != MODES_OK || (rc2 = lens.reserve (want)) != MODES_OK || (rc2 = poss.reserve (want)) != MODES_OK) {
+      sums.release (); lens.release (); poss.release ();
+      return rc2;
+    }
+    const size_t keep = std::min (n, std::min (e->pin_sums.cap, e->pin_rlen.cap));
+    if (keep) { memcpy (sums.p, e->pin_sums.p, keep * sizeof (uint64_t)); memcpy (lens.p, e->pin_rlen.p, keep * sizeof (uint32_t)); }
+    e->pin_sums.release (); e->pin_sums = sums;
+    e->pin_rlen.release (); e->pin_rlen = lens;
+    e->pin_rpos.release (); e->pin_rpos = poss;
+    if ((rc2 = e->rssi_pos.reserve (want)) != MODES_OK) return rc2;
+    if ((rc2 = e->rssi_len.reserve (want)) != MODES_OK) return rc2;
+    return e->rssi_sum.reserve (want);
+  };
   size_t nsums = 0;
   uint64_t all_win = 0, all_rec = 0;
   double host_ms = 0.0;
@@ -1438,7 +1485,9 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   e->messages.reserve (e->d8_last_msgs + e->d8_last_msgs / 8 + 64);
   for (uint32_t r = 0; r < nranges; r++) {
     const uint32_t c0 = lo[r], c1 = lo[r + 1];
+    const auto t_wait0 = std::chrono::steady_clock::now ();
     HIP_TRY (hipEventSynchronize (e->d8_gathered[r]));
+    if (timing) fprintf (stderr, "  %.3f ms: range %u: waited %.3f ms for the device", since_entry (), r, std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - t_wait0).count ());
     if (r == 0 && e->d8_planes_timed) (void) hipEventElapsedTime (&e->kernel_ms[1], e->ev[2], e->ev[3]);
     float wms = 0;
     (void) hipEventElapsedTime (&wms, e->d8_events[3 * r], e->d8_events[3 * r + 1]);
@@ -1466,55 +1515,56 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
       wins = e->pin_wins2.p; recs = e->pin_recs2.p;
     }
     const auto t_host0 = std::chrono::steady_clock::now ();
-    rpos.clear (); rlen.clear ();
-    accept_pass_8000_with (wins, nwin, recs, B, q.bshift, T, e->ov, first_sample, e->cfg.sample_rate,
-      [&] (const Record &rr, int) { return score_record (rr, e->cache); },
-      [&] (const Record &rr, uint64_t, modes_message *out) { return accept_record (rr, e->cache, out); },
-      [&] (modes_message &m, const Record &, uint64_t blkc, int m_start, int slen) {
-        if (!m.addr) return;                                        // ref: src/demod-8000.c:487
-        if (m_start >= 0) {
-          rpos.push_back (blkc * B + uint64_t (m_start) - 19);      // the shared kernel sums from position + 19
-          rlen.push_back (uint32_t (slen));
-          level_of.push_back (LevelOf { e->messages.size (), nsums + rpos.size () - 1, uint32_t (slen) });
-        }
-        e->messages.push_back (m);
-      }, ps);
-    host_ms += std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - t_host0).count ();
-    // signal level of the range's messages (ref: :469-484): queued behind the walk, read when all ranges are done
-    const size_t nr = rpos.size ();
-    if (nr) {
-      if (nr > e->rssi_pos.cap || nr > e->rssi_len.cap || nr > e->rssi_sum.cap || nsums + nr > e->pin_sums.cap ||
-          nr > e->pin_rpos.cap || nr > e->pin_rlen.cap)
-        HIP_TRY (hipStreamSynchronize (lvl));                     // nothing of an earlier range is left in what grows
-      if ((rc = e->rssi_pos.reserve (nr)) != MODES_OK) return rc;
-      if ((rc = e->rssi_len.reserve (nr)) != MODES_OK) return rc;
-      if ((rc = e->rssi_sum.reserve (nr)) != MODES_OK) return rc;
-      if (nsums + nr > e->pin_sums.cap) {
-        PinBuf<uint64_t> bigger;
-        if ((rc = bigger.reserve (2 * (nsums + nr))) != MODES_OK) return rc;
-        if (nsums) memcpy (bigger.p, e->pin_sums.p, nsums * sizeof (uint64_t));
-        e->pin_sums.release ();
-        e->pin_sums = bigger;
+    // every live window yields at most one message: room for all of them, trimmed behind the walk
+    if ((rc = level_room (nsums + nwin)) != MODES_OK) return rc;
+    const size_t m0 = e->messages.size ();
+    e->messages.resize (m0 + nwin);
+    if (lvl_msg.size () < nsums + nwin) lvl_msg.resize (nsums + nwin + (nsums + nwin) / 4);
+    {
+      modes_message *const mout = e->messages.data () + m0;
+      uint64_t *const rp = e->pin_rpos.p + nsums;
+      uint32_t *const rl = e->pin_rlen.p + nsums, *const lm = lvl_msg.data () + nsums;
+      size_t nm = 0, nr = 0;
+      IcaoCache &cache = e->cache;
+      accept_pass_8000_with (wins, nwin, recs, B, q.bshift, T, e->ov, first_sample, e->cfg.sample_rate,
+        [&] (const Record &rr, int) { return score_record (rr, cache); },
+        [&] (const Record &rr, uint64_t, modes_message *out) { return accept_record (rr, cache, out); },
+        [&] (modes_message &m, const Record &, uint64_t blkc, int m_start, int slen) {
+          if (!m.addr) return;                                      // ref: src/demod-8000.c:487
+          if (m_start >= 0) {
+            rp[nr] = blkc * B + uint64_t (m_start) - 19;            // the shared kernel sums from position + 19
+            rl[nr] = uint32_t (slen);
+            lm[nr] = uint32_t (m0 + nm);
+            nr++;
+          }
+          nm++;                                                     // the message stays where it was built
+        },
+        [&] { return mout + nm; }, ps);
+      e->messages.resize (m0 + nm);
+      host_ms += std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - t_host0).count ();
+      if (timing) fprintf (stderr, ", walked %llu windows / %llu records in %.3f ms", (unsigned long long) nwin, (unsigned long long) nrec,
+                           std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - t_host0).count ());
+      // signal level of the range's messages (ref: :469-484): queued behind the walk, read when all ranges are done
+      if (nr) {
+        HIP_TRY (hipMemcpyAsync (e->rssi_pos.p + nsums, rp, nr * sizeof (uint64_t), hipMemcpyHostToDevice, lvl));
+        HIP_TRY (hipMemcpyAsync (e->rssi_len.p + nsums, rl, nr * sizeof (uint32_t), hipMemcpyHostToDevice, lvl));
+        HIP_TRY (launch_rssi2400 (sp.conv, sp.iq, sp.conv == kConvMagU16 ? sp.navail : sp.nsamples, sp.halo, sp.ov, sp.block_samples,
+                                  sp.lut256, e->rssi_pos.p + nsums, e->rssi_len.p + nsums, e->rssi_sum.p + nsums, uint32_t (nr), lvl));
+        HIP_TRY (hipMemcpyAsync (e->pin_sums.p + nsums, e->rssi_sum.p + nsums, nr * sizeof (uint64_t), hipMemcpyDeviceToHost, lvl));
+        nsums += nr;
       }
-      if ((rc = e->pin_rpos.reserve (nr)) != MODES_OK) return rc;
-      if ((rc = e->pin_rlen.reserve (nr)) != MODES_OK) return rc;
-      HIP_TRY (hipStreamSynchronize (lvl));                       // (idle by now) the staging buffers are reused range by range
-      memcpy (e->pin_rpos.p, rpos.data (), nr * sizeof (uint64_t));
-      memcpy (e->pin_rlen.p, rlen.data (), nr * sizeof (uint32_t));
-      HIP_TRY (hipMemcpyAsync (e->rssi_pos.p, e->pin_rpos.p, nr * sizeof (uint64_t), hipMemcpyHostToDevice, lvl));
-      HIP_TRY (hipMemcpyAsync (e->rssi_len.p, e->pin_rlen.p, nr * sizeof (uint32_t), hipMemcpyHostToDevice, lvl));
-      HIP_TRY (launch_rssi2400 (sp.conv, sp.iq, sp.conv == kConvMagU16 ? sp.navail : sp.nsamples, sp.halo, sp.ov, sp.block_samples,
-                                sp.lut256, e->rssi_pos.p, e->rssi_len.p, e->rssi_sum.p, uint32_t (nr), lvl));
-      HIP_TRY (hipMemcpyAsync (e->pin_sums.p + nsums, e->rssi_sum.p, nr * sizeof (uint64_t), hipMemcpyDeviceToHost, lvl));
-      nsums += nr;
     }
+    const auto t_lvl0 = t_host0;
+    if (timing) fprintf (stderr, ", levels queued in %.3f ms\n", std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - t_lvl0).count ());
   }
+  const auto t_end0 = std::chrono::steady_clock::now ();
   HIP_TRY (hipStreamSynchronize (lvl));
   HIP_TRY (hipStreamSynchronize (stream));
+  if (timing) fprintf (stderr, "  %.3f ms: end: %.3f ms for the streams to drain\n", since_entry (), std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - t_end0).count ());
   e->d8_win_gen = e->d8_planes_gen; e->d8_win_pending = (long long) q.pending; e->d8_win_tail = trig_tail_in;
   e->d8_last_chunks = nchunks; e->d8_last_nwin = all_win; e->d8_last_nrec = all_rec; e->d8_last_msgs = e->messages.size ();
-  for (const LevelOf &lv : level_of)
-    e->messages[lv.msg].sig_level = (double (e->pin_sums.p[lv.sum]) / 65535.0 / 65535.0) / double (lv.len);
+  for (size_t i = 0; i < nsums; i++)
+    e->messages[lvl_msg[i]].sig_level = (double (e->pin_sums.p[i]) / 65535.0 / 65535.0) / double (e->pin_rlen.p[i]);
   {
     // the hand-over state (the copies were queued in front of the first range: long done)
     modes_d8_state &o = e->d8_out;
@@ -1538,7 +1588,7 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
     o.acc = 0; o.acc_valid = 0;
     e->d8_have_run = true;
   }
-  if (getenv ("MODES_TIMING")) fprintf (stderr, "run_8000: ordered pass %.3f ms in %u ranges, %zu messages\n", host_ms, nranges, e->messages.size ());
+  if (timing) fprintf (stderr, "  %.3f ms: run_8000: ordered pass %.3f ms in %u ranges, %zu messages\n", since_entry (), host_ms, nranges, e->messages.size ());
   e->stats.valid_preamble = ps.valid_preamble; e->stats.demodulated = ps.demodulated;
   e->stats.CRC_good = ps.CRC_good; e->stats.CRC_bad = ps.CRC_bad; e->stats.CRC_single_bit_fix = ps.CRC_single_bit_fix;
   e->stats.CRC_two_bits_fix = ps.CRC_two_bits_fix; e->stats.CRC_fixed = ps.CRC_single_bit_fix + ps.CRC_two_bits_fix;

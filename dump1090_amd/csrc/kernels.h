@@ -26,7 +26,7 @@ hipError_t launch_d8_chain_table (const D8Params &q, hipStream_t stream);
 hipError_t launch_d8_chain_exit (const D8Params &q, int32_t *exit_of, hipStream_t stream);
 hipError_t launch_d8_chain (const D8Params &q, unsigned long long trig_tail, long long search0, long long *pre,
                             long long *pending_out, hipStream_t stream);
-hipError_t launch_d8_windows (const D8Params &q, uint32_t nch, hipStream_t stream);   // chunks q.chunk0 .. + nch
+hipError_t launch_d8_windows (const D8Params &q, uint32_t nch, hipStream_t stream, int which = 3);   // chunks q.chunk0 .. + nch; 1: inside a block, 2: at a block edge
 hipError_t launch_d8_tail (const D8Params &q, int32_t *dnext, hipStream_t stream);
 hipError_t launch_d8_seed (uint32_t *announce, const uint32_t *addr, uint32_t n, hipStream_t stream);
 hipError_t launch_d8_count (const D8Params &q, uint32_t nch, uint32_t *chunk_rec, hipStream_t stream);

@@ -31,6 +31,7 @@ constexpr int kWinTile = 1952;                                   // 8 * 241 + 4 
 
 // D'[g]: the difference stream in the look-ahead domain of the reference's `dbuf = d8m_dbuf + D8M_LOOK_BACK`
 // (ref: :208-222): D'[g] = D[g - 544].  tile[x - x0] = V[x], the magnitudes in scan-position coordinates.
+template <bool PAD = false>
 __device__ __forceinline__ int dprime_tile (const D8Params &q, const uint16_t *tile, long long x0, long long g)
 {
   if (g < kD8LookAhead) return (q.dprev && g >= -kD8LookBack) ? q.dprev[g + kD8LookBack] : 0;
@@ -40,13 +41,14 @@ __device__ __forceinline__ int dprime_tile (const D8Params &q, const uint16_t *t
   const uint64_t blk = q.bshift >= 63 ? 0 : P >> q.bshift;
   const uint64_t j = P - blk * B;
   const uint64_t mlen = min (B, q.T - blk * B);
-  int v = tile[(long long) P - x0];
-  if (j + 4 < mlen) v -= tile[(long long) P + 4 - x0];             // the last 4 of a block stay raw (ref: :210-215)
+  const int i = int ((long long) P - x0);
+  int v = tile[PAD ? tile_pad (i) : i];
+  if (j + 4 < mlen) v -= tile[PAD ? tile_pad (i + 4) : i + 4];     // the last 4 of a block stay raw (ref: :210-215)
   return v;
 }
 
 struct TrigLds {
-  uint16_t tile[kTrigTile];
+  uint16_t tile[kTrigTile + 8 * (kTrigTile / 256 + 1)];   // padded: sample i at tile_pad (i)
   uint16_t lut[256];
 };
 
@@ -56,6 +58,19 @@ struct WinLds {
   uint8_t  par[kD8Win + 8];
   uint16_t lut[256];
 };
+
+// The windows at a block edge (d8_window_edge_kernel): their differences come from three places (this call's magnitudes,
+// the differences carried in, what the previous call left in the buffer), so they are formed once, by all lanes side by
+// side, and the window reads them here.
+constexpr int kWinDiffs = kWinRows * 8 + 8;
+struct WinEdgeLds {
+  WinLds  base;
+  int32_t diff[kWinDiffs];
+};
+__device__ __forceinline__ WinLds &base_of (WinLds &w) { return w; }
+__device__ __forceinline__ WinLds &base_of (WinEdgeLds &w) { return w.base; }
+__device__ __forceinline__ int32_t *diffs_of (WinLds &) { return nullptr; }
+__device__ __forceinline__ int32_t *diffs_of (WinEdgeLds &w) { return w.diff; }
 
 // |a - b| + c in one VALU operation (v_sad_u32); the compiler does not form it from the C expression
 __device__ __forceinline__ uint32_t sad_u32 (uint32_t a, uint32_t b, uint32_t c)
@@ -95,11 +110,9 @@ __device__ __forceinline__ int table_lookup8 (const ErrEntry *tab, int n, uint32
 // ---------------------------------------------------------------------------------------------
 // per step: the 8 sliding sums, their maximum, and whether the search would open a window there
 // ---------------------------------------------------------------------------------------------
-template <int CONV>
-__global__ __launch_bounds__ (64 * kW8)
-void d8_trig_kernel (const D8Params q, uint64_t strip_limit)
+template <int CONV, bool ARRAYS>
+__device__ __forceinline__ void d8_trig_body (const D8Params &q, uint64_t strip_limit, TrigLds *lds)
 {
-  __shared__ TrigLds lds[kW8];
   const int lane = lane_id ();
   const int wv = threadIdx.x >> 6;
   TrigLds &w = lds[wv];
@@ -112,45 +125,58 @@ void d8_trig_kernel (const D8Params q, uint64_t strip_limit)
   const long long g0 = 8 * (n0 + 1);                                        // first difference of row 0
   const long long xlo = g0 - kD8LookAhead;                                  // its scan position (may be < 0)
   const long long slo = xlo - (long long) (CONV == kConvMagU16 ? 0u : q.sp.ov);
-  const long long a_lo = (slo >= 0 ? slo : slo - 15) / 16 * 16;
+  const long long a_lo = (slo >= 0 ? slo : slo - 7) / 8 * 8;                // == slo: steps are 8 samples and the overlap a multiple of 8
   const long long x0 = xlo - (slo - a_lo);
-  stage_tile<CONV, kTrigTile> (w.tile, w.lut, q.sp, a_lo, lane);
+  // The tile is padded by 16 bytes behind every 256 samples: the eight segments below read it 256 samples apart, which
+  // without the padding is one LDS bank for all of them.
+  stage_tile<CONV, kTrigTile, true> (w.tile, w.lut, q.sp, a_lo, lane);
   __builtin_amdgcn_s_waitcnt (0xc07f);
   __builtin_amdgcn_wave_barrier ();
 
   // `plain`: every difference of the strip is m[j] - m[j+4] inside one block of the stream (see d8_window_kernel)
   const long long Plo = g0 - kD8LookAhead, Phi = Plo + kTrigRows * 8;
-  bool plain = Plo >= 0 && uint64_t (Phi) + 4 < q.T;
+  bool plain = Plo >= 0 && uint64_t (Phi) + 4 < q.T && Plo == x0;            // row 0 at tile index 0: the padding falls between rows
   if (plain && q.bshift < 63) plain = (uint64_t (Plo) >> q.bshift) == ((uint64_t (Phi) + 4) >> q.bshift);
 
   // Lane = segment * 8 + column: eight segments of 32 steps slide their own 56-row window sum (ref: :235-271), the
   // eight sums of a step sit in eight neighbouring lanes.
   static_assert (kD8StripSteps == 256, "eight segments of 32 steps");
   const int col = lane & 7, seg = lane >> 3, t0 = seg * 32;
-  uint32_t on_bits = 0, am_bits = 0;
+  // The two bit rows are shifted in step by step, newest at the bottom: `over` takes the sign of kD8Ambig - max (max above
+  // the ambiguity bound), `zero` the sign of max - 1 (sums stay below 2^23).  Reversed and masked to the steps that exist
+  // behind the loop; an ambiguous step is one that is neither.
+  uint32_t over = 0, zero = 0;
   auto step_out = [&] (int u, uint32_t psum) {
     uint32_t mxv = psum;
     mxv = max (mxv, dpp_mov<0xB1> (mxv));                // quad_perm [1,0,3,2]
     mxv = max (mxv, dpp_mov<0x4E> (mxv));                // quad_perm [2,3,0,1]
     mxv = max (mxv, dpp_mov<0x141> (mxv));               // row_half_mirror: the other quad of the eight
-    const long long n = n0 + t0 + u;
-    const bool valid = uint64_t (n) < q.nsteps;
-    if (valid && mxv > uint32_t (kD8Ambig)) on_bits |= 1u << u;
-    if (valid && mxv > 0 && mxv <= uint32_t (kD8Ambig)) am_bits |= 1u << u;
-    if (q.write_arrays && valid && col == 0) { q.p0[n] = psum; q.mx[n] = mxv; }
+    over = __builtin_amdgcn_alignbit (over, uint32_t (kD8Ambig) - mxv, 31);
+    zero = __builtin_amdgcn_alignbit (zero, mxv - 1u, 31);
+    if constexpr (ARRAYS) {
+      const long long n = n0 + t0 + u;
+      if (uint64_t (n) < q.nsteps && col == 0) { q.p0[n] = psum; q.mx[n] = mxv; }
+    }
   };
   if (plain) {
-    const uint16_t *tp = w.tile + int (Plo - x0) + col + 8 * t0;             // row r of this lane's segment: tp[8 r], tp[8 r + 4]
+    // row r of this lane's segment: samples 8 (t0 + r) + col and + 4 of the tile; t0 = 32 seg, so the segment's base
+    // carries seg paddings and the rest of tile_pad () is a compile-time constant per r
+    const uint16_t *tp = w.tile + col + (8 * 32 + 8) * seg;
+    const int cross = col >= 4 ? 8 : 0;      // the partner 4 samples on lies behind a padding when the row ends a 256-sample group
+#define TP(r) tp[tile_pad (8 * (r))]
+#define TQ(r) tp[tile_pad (8 * (r)) + 4 + ((((r) & 31) == 31) ? cross : 0)]
     uint32_t psum = 0;
-#pragma unroll 8
-    for (int r = 0; r < 56; r++) psum = sad_u32 (tp[8 * r], tp[8 * r + 4], psum);         // v_sad_u32: |a - b| + c in one operation
-#pragma unroll 8
+#pragma unroll
+    for (int r = 0; r < 56; r++) psum = sad_u32 (TP (r), TQ (r), psum);                   // v_sad_u32: |a - b| + c in one operation
+#pragma unroll
     for (int u = 0; u < 32; u++) {
       step_out (u, psum);
-      psum = sad_u32 (tp[8 * (u + 56)], tp[8 * (u + 56) + 4], psum) - sad_u32 (tp[8 * u], tp[8 * u + 4], 0u);
+      psum = sad_u32 (TP (u + 56), TQ (u + 56), psum) - sad_u32 (TP (u), TQ (u), 0u);
     }
+#undef TP
+#undef TQ
   } else {
-    auto absd = [&] (int row) -> uint32_t { const int d = dprime_tile (q, w.tile, x0, g0 + 8 * row + col); return uint32_t (d < 0 ? -d : d); };
+    auto absd = [&] (int row) -> uint32_t { const int d = dprime_tile<true> (q, w.tile, x0, g0 + 8 * row + col); return uint32_t (d < 0 ? -d : d); };
     uint32_t psum = 0;
     for (int r = 0; r < 56; r++) psum += absd (t0 + r);
     for (int u = 0; u < 32; u++) {
@@ -158,6 +184,9 @@ void d8_trig_kernel (const D8Params q, uint64_t strip_limit)
       if (u + 1 < 32) psum += absd (t0 + u + 56) - absd (t0 + u);
     }
   }
+  const long long left = (long long) q.nsteps - (n0 + t0);
+  const uint32_t exist = left >= 32 ? ~0u : left <= 0 ? 0u : (1u << int (left)) - 1u;
+  const uint32_t on_bits = __brev (over) & exist, am_bits = ~__brev (over | zero) & exist;
   // word (n0 >> 6) + seg / 2 of the bit arrays, half seg & 1: every lane of a segment holds the same 32 bits
   if (col == 0) {
     reinterpret_cast<uint32_t *> (q.trig)[(n0 >> 5) + seg] = on_bits;
@@ -166,6 +195,23 @@ void d8_trig_kernel (const D8Params q, uint64_t strip_limit)
   uint32_t namb = col == 0 ? uint32_t (__popc (am_bits)) : 0u;
   for (int d = 32; d >= 1; d >>= 1) namb += uint32_t (__shfl_xor (int (namb), d, 64));
   if (lane == 0 && namb) atomicAdd (q.amb_count, namb);
+}
+
+template <int CONV>
+__global__ __launch_bounds__ (64 * kW8)
+void d8_trig_kernel (const D8Params q, uint64_t strip_limit)
+{
+  __shared__ TrigLds lds[kW8];
+  d8_trig_body<CONV, false> (q, strip_limit, lds);
+}
+
+// the same, and the per-step sums and maxima written out (drop-in boundary, the slow average's steps)
+template <int CONV>
+__global__ __launch_bounds__ (64 * kW8)
+void d8_trig_arrays_kernel (const D8Params q, uint64_t strip_limit)
+{
+  __shared__ TrigLds lds[kW8];
+  d8_trig_body<CONV, true> (q, strip_limit, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -340,51 +386,70 @@ void d8_chain_walk_kernel (const D8Params q, const long long *pre, long long *pe
 // ---------------------------------------------------------------------------------------------
 // one completed window per wave (ref: :331-420): match curve, peak, the two search strings, 32 candidates
 // ---------------------------------------------------------------------------------------------
-#ifndef D8WIN_WAVES
-#define D8WIN_WAVES 4
-#endif
-template <int CONV>
-__global__ __launch_bounds__ (64 * kW8) __attribute__ ((amdgpu_waves_per_eu (D8WIN_WAVES, D8WIN_WAVES)))
-void d8_window_kernel (const D8Params q)
+// PLAIN: only the windows whose differences are all m[j] - m[j+4] inside one block of the stream (all but a few per
+// block); !PLAIN: only the others.  Two kernels, so that the rare window's block edges, carried-in differences and
+// stale buffer contents cost the common one neither registers nor branches.
+template <int CONV, bool PLAIN, typename Lds>
+__device__ __forceinline__ void d8_window_body (const D8Params &q, Lds *lds, uint32_t *crc_tab)
 {
-  __shared__ WinLds lds[kW8];
-  __shared__ uint32_t crc_tab[256];
-  const int lane = lane_id ();
+  const int lane0 = lane_id ();
   const int wv = threadIdx.x >> 6;
-  WinLds &w = lds[wv];
+  WinLds &w = base_of (lds[wv]);
+  int32_t *const diff = diffs_of (lds[wv]);
   crc_tab[threadIdx.x & 255] = q.sp.crc_table[threadIdx.x & 255];
   __syncthreads ();
   const uint32_t chunk = q.chunk0 + blockIdx.x;
   const uint32_t nwin = min (q.win_count[chunk], uint32_t (kD8WinCap));
-  for (int i = lane; i < 256; i += 64) w.lut[i] = q.sp.lut256 ? q.sp.lut256[i] : uint16_t (0);
+  for (int i = lane0; i < 256; i += 64) w.lut[i] = q.sp.lut256 ? q.sp.lut256[i] : uint16_t (0);
 
-  for (uint32_t k = blockIdx.y * kW8 + wv; k < nwin; k += gridDim.y * kW8) {
-    const long long s = q.win_start[size_t (chunk) * kD8WinCap + k];
+  // The block whose demod_8000 call completes the window that opens at step s, and how far that call's buffer is filled
+  // (ref: :203-215); `plain`: every difference of the window is m[j] - m[j+4] inside one block of the stream (no block
+  // edge, no carried-in differences, nothing beyond what the call wrote).
+  const uint64_t B = q.sp.block_samples;
+  auto block_of = [&] (long long s) -> uint64_t { return q.bshift >= 63 ? 0 : uint64_t (8 * (s + kD8Win - 1)) >> q.bshift; };   // by sptr of the last recorded step
+  auto fill_of = [&] (uint64_t blkc) -> long long { return (long long) (blkc * B + min (B, q.T - blkc * B)) + kD8LookAhead; };
+  auto plain_of = [&] (long long s) -> bool {
+    const long long gbase = 8 * (s - 4), Plo = gbase - kD8LookAhead, Phi = Plo + kWinRows * 8 + 8;
+    bool plain = Plo >= 0 && uint64_t (Phi) + 4 < q.T && gbase + kWinRows * 8 + 8 < fill_of (block_of (s));
+    if (plain && q.bshift < 63) plain = (uint64_t (Plo) >> q.bshift) == ((uint64_t (Phi) + 4) >> q.bshift);
+    return plain;
+  };
+
+  // The windows of a chunk go round the waves of its workgroups.  Lane j looks at the j-th window of this wave: which of
+  // them are this kernel's is settled for all of them at once, and each one's opening step is then a scalar.
+  const uint32_t stride = gridDim.y * kW8;
+  for (uint32_t kb = blockIdx.y * kW8 + wv; kb < nwin; kb += 64 * stride) {
+  const uint32_t kl = kb + uint32_t (lane0) * stride;
+  long long s_lane = 0;
+  bool mine = false;
+  if (kl < nwin) { s_lane = q.win_start[size_t (chunk) * kD8WinCap + kl]; mine = plain_of (s_lane) == PLAIN; }
+  u64 todo = __ballot (mine);
+  while (todo) {
+    const int pick = __builtin_ctzll (todo);
+    todo &= todo - 1;
+    const uint32_t k = kb + uint32_t (pick) * stride;
+    const long long s = (long long) (u64 (uint32_t (__builtin_amdgcn_readlane (int (uint32_t (u64 (s_lane))), pick)))
+                                     | u64 (uint32_t (__builtin_amdgcn_readlane (int (uint32_t (u64 (s_lane) >> 32)), pick))) << 32);
+    // the lane number is made opaque per window: what derives from it (shuffle addresses, masks, LDS offsets) is then
+    // formed where it is used instead of being held in registers across the whole loop, which cost two waves per SIMD
+    int lane = lane0;
+    asm volatile ("" : "+v" (lane));
     const long long gbase = 8 * (s - 4);                                     // dw[0] = D'[gbase]
     const long long xlo = gbase - kD8LookAhead;
     const long long slo = xlo - (long long) (CONV == kConvMagU16 ? 0u : q.sp.ov);
     const long long a_lo = (slo >= 0 ? slo : slo - 15) / 16 * 16;
     const long long x0 = xlo - (slo - a_lo);
+    const uint64_t blkc = block_of (s);
+    const long long fill_g = fill_of (blkc);
+    const long long Plo = gbase - kD8LookAhead;
+
     __builtin_amdgcn_s_waitcnt (0xc07f);
     __builtin_amdgcn_wave_barrier ();
     stage_tile<CONV, kWinTile> (w.tile, w.lut, q.sp, a_lo, lane);
     __builtin_amdgcn_s_waitcnt (0xc07f);
     __builtin_amdgcn_wave_barrier ();
-
-    // the block whose demod_8000 call completes the window, and how far that call's buffer is filled (ref: :203-215)
-    const uint64_t B = q.sp.block_samples;
-    const uint64_t done = uint64_t (8 * (s + kD8Win - 1));                   // sptr of the last recorded step
-    const uint64_t blkc = q.bshift >= 63 ? 0 : done >> q.bshift;
-    const uint64_t mlen_c = min (B, q.T - blkc * B);
-    const long long fill_g = (long long) (blkc * B + mlen_c) + kD8LookAhead;
-    // D'[gbase + idx]; `plain`: every difference of the window is m[j] - m[j+4] inside one block of the stream (no block
-    // edge, no carried-in differences, nothing beyond what the call wrote) -- all but a few windows per block
-    const long long Plo = gbase - kD8LookAhead, Phi = Plo + kWinRows * 8 + 8;
-    bool plain = Plo >= 0 && uint64_t (Phi) + 4 < q.T && gbase + kWinRows * 8 + 8 < fill_g;
-    if (plain && q.bshift < 63) plain = (uint64_t (Plo) >> q.bshift) == ((uint64_t (Phi) + 4) >> q.bshift);
     const int tbase = int (Plo - x0);                                        // tile index of the sample behind D'[gbase]
-    auto dval = [&] (int idx) -> int {
-      if (plain) return int (w.tile[tbase + idx]) - int (w.tile[tbase + idx + 4]);
+    auto dval_edge = [&] (int idx) -> int {
       const long long g = gbase + idx;
       if (g < fill_g) return dprime_tile (q, w.tile, x0, g);
       // beyond what this call wrote: the buffer still holds what the previous call put at that index, or the
@@ -398,6 +463,15 @@ void d8_window_kernel (const D8Params q)
         if (jj + 4 < B) d -= mag_of_V<CONV> (q.sp.iq, q.sp.nsamples, q.sp.halo, q.sp.ov, q.sp.block_samples, q.sp.lut256, xp + 4);
       }
       return d;
+    };
+    if constexpr (!PLAIN) {
+      for (int i = lane; i < kWinDiffs; i += 64) diff[i] = dval_edge (i);
+      __builtin_amdgcn_s_waitcnt (0xc07f);
+      __builtin_amdgcn_wave_barrier ();
+    }
+    auto dval = [&] (int idx) -> int {
+      if constexpr (PLAIN) return int (w.tile[tbase + idx]) - int (w.tile[tbase + idx + 4]);
+      else return diff[idx];
     };
 
     // phase sums of steps s .. s+167 (ref: :235-271): ph_i(t) = sum over rows t .. t+55 of |D'| in column i, rows counted
@@ -416,7 +490,7 @@ void d8_window_kernel (const D8Params q)
       if (col == 0) w.par[t] = uint8_t (best);
       if (col == start_phase) w.match[t] = int (psum);
     };
-    if (plain) {
+    if constexpr (PLAIN) {
       const uint16_t *tp = w.tile + tbase + 5 * 8 + col + 8 * t0;            // row r of this lane's segment: tp[8 r], tp[8 r + 4]
       uint32_t psum = 0;
 #pragma unroll 8
@@ -536,6 +610,25 @@ void d8_window_kernel (const D8Params q)
       q.windows[slot] = h;
     }
   }
+  }
+}
+
+template <int CONV>
+__global__ __launch_bounds__ (64 * kW8) __attribute__ ((amdgpu_waves_per_eu (6, 6)))     // 80 registers, nothing spilled
+void d8_window_kernel (const D8Params q)
+{
+  __shared__ WinLds lds[kW8];
+  __shared__ uint32_t crc_tab[256];
+  d8_window_body<CONV, true> (q, lds, crc_tab);
+}
+
+template <int CONV>
+__global__ __launch_bounds__ (64 * kW8)
+void d8_window_edge_kernel (const D8Params q)
+{
+  __shared__ WinEdgeLds lds[kW8];
+  __shared__ uint32_t crc_tab[256];
+  d8_window_body<CONV, false> (q, lds, crc_tab);
 }
 
 // the last kD8Overlap differences of the stream, for the next call (ref: :509)
@@ -607,33 +700,25 @@ __device__ __forceinline__ bool record_relevant (const Record &r, const uint32_t
 }
 
 // ---- compaction of the per-window slots into two dense arrays, window order kept ----
+// One thread per window slot; chunk_rec[c] (records that survive) and chunk_rec[nchunks + c] (windows left with something
+// to score) are summed with one atomic per wave: the launcher clears them first.
+constexpr int kCountBlocks = (kD8WinCap + 255) / 256;
 __global__ __launch_bounds__ (256)
 void d8_count_kernel (const D8Params q, uint32_t *chunk_rec)
 {
-  __shared__ uint32_t part[256];
   const uint32_t c = q.chunk0 + blockIdx.x, nwin = min (q.win_count[c], uint32_t (kD8WinCap));
-  uint32_t sum = 0;
-  for (uint32_t k = threadIdx.x; k < nwin; k += 256) {
+  const uint32_t k = blockIdx.y * 256 + threadIdx.x;
+  uint32_t live = 0;
+  if (k < nwin) {
     D8Window &h = q.windows[size_t (c) * kD8WinCap + k];
     Record *src = q.records + (size_t (c) * kD8WinCap + k) * kD8Cand;
-    uint32_t live = 0;
     // the verdict is kept in the record: the gather must see what was counted, whatever later windows announce meanwhile
     for (uint32_t r = 0; r < h.nrec; r++) { const bool rel = record_relevant (src[r], q.announce); src[r].flags = rel; live += rel; }
     h.pad = live;                                              // records that survive the filter
-    sum += live;
   }
-  part[threadIdx.x] = sum;
-  __syncthreads ();
-  for (int d = 128; d >= 1; d >>= 1) { if (threadIdx.x < (unsigned) d) part[threadIdx.x] += part[threadIdx.x + d]; __syncthreads (); }
-  if (threadIdx.x == 0) chunk_rec[c] = part[0];
-  // windows left with something to score
-  __syncthreads ();
-  uint32_t lw = 0;
-  for (uint32_t k = threadIdx.x; k < nwin; k += 256) lw += q.windows[size_t (c) * kD8WinCap + k].pad != 0;
-  part[threadIdx.x] = lw;
-  __syncthreads ();
-  for (int d = 128; d >= 1; d >>= 1) { if (threadIdx.x < (unsigned) d) part[threadIdx.x] += part[threadIdx.x + d]; __syncthreads (); }
-  if (threadIdx.x == 0) chunk_rec[q.nchunks + c] = part[0];
+  uint32_t recs = live, wins = live != 0;
+  for (int d = 32; d >= 1; d >>= 1) { recs += uint32_t (__shfl_xor (int (recs), d, 64)); wins += uint32_t (__shfl_xor (int (wins), d, 64)); }
+  if ((threadIdx.x & 63) == 0 && wins) { atomicAdd (&chunk_rec[c], recs); atomicAdd (&chunk_rec[q.nchunks + c], wins); }
 }
 
 // Where each chunk of a range of chunks puts its live windows and records in the range's packed arrays (one wave).
@@ -712,7 +797,11 @@ void d8_gather_kernel (const D8Params q, const uint64_t *win_off, const uint64_t
 
 hipError_t launch_d8_count (const D8Params &q, uint32_t nch, uint32_t *chunk_rec, hipStream_t stream)
 {
-  if (nch) hipLaunchKernelGGL (d8_count_kernel, dim3 (nch), dim3 (256), 0, stream, q, chunk_rec);
+  if (!nch) return hipSuccess;
+  hipError_t he = hipMemsetAsync (chunk_rec + q.chunk0, 0, nch * sizeof (uint32_t), stream);
+  if (he == hipSuccess) he = hipMemsetAsync (chunk_rec + q.nchunks + q.chunk0, 0, nch * sizeof (uint32_t), stream);
+  if (he != hipSuccess) return he;
+  hipLaunchKernelGGL (d8_count_kernel, dim3 (nch, kCountBlocks), dim3 (256), 0, stream, q, chunk_rec);
   return hipGetLastError ();
 }
 
@@ -746,7 +835,8 @@ hipError_t launch_d8_trig (const D8Params &q, uint64_t step_limit, hipStream_t s
   uint64_t nstrips = (q.nsteps + kD8StripSteps - 1) / kD8StripSteps;
   if (step_limit) nstrips = min (nstrips, (step_limit + kD8StripSteps - 1) / kD8StripSteps);
   const dim3 grid ((unsigned) ((nstrips + kW8 - 1) / kW8)), block (64 * kW8);
-  D8_DISPATCH (d8_trig_kernel, grid, block, q, nstrips);
+  if (q.write_arrays) { D8_DISPATCH (d8_trig_arrays_kernel, grid, block, q, nstrips); }
+  else { D8_DISPATCH (d8_trig_kernel, grid, block, q, nstrips); }
   return hipGetLastError ();
 }
 
@@ -777,11 +867,15 @@ hipError_t launch_d8_chain (const D8Params &q, unsigned long long trig_tail, lon
   return hipGetLastError ();
 }
 
-hipError_t launch_d8_windows (const D8Params &q, uint32_t nch, hipStream_t stream)
+// `which`: 1 = the windows inside one block, 2 = the windows at a block edge, 3 = both
+hipError_t launch_d8_windows (const D8Params &q, uint32_t nch, hipStream_t stream, int which)
 {
   if (nch == 0) return hipSuccess;
   const dim3 grid (nch, 16), block (64 * kW8);
-  D8_DISPATCH (d8_window_kernel, grid, block, q);
+  if (which & 1) { D8_DISPATCH (d8_window_kernel, grid, block, q); }
+  // a few windows per block edge: fewer, longer-lived waves (each looks at 64 windows per pass)
+  const dim3 edge_grid (nch, 4);
+  if (which & 2) { D8_DISPATCH (d8_window_edge_kernel, edge_grid, block, q); }
   return hipGetLastError ();
 }
 
