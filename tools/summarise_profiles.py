@@ -40,6 +40,10 @@ if bad:
     sys.exit("kernel stats and bench line differ by more than 10 %% for: %s" % ", ".join(bad))
 
 hbm = {}
+try:                                   # a partial refresh (collect_profiles.sh all <workload>) keeps the other workloads' entries
+    hbm = {k: v for k, v in json.load(open("%s/%s_pmc_hbm.json" % (out, tag))).items() if k != "note"}
+except (OSError, ValueError):
+    pass
 for f in sorted(glob.glob(raw + "/FETCH_SIZE_*.json")):
     wl = os.path.basename(f)[len("FETCH_SIZE_"):-5]
     res = {}
