@@ -18,7 +18,7 @@ constexpr int kTileAC = kStrip + kLookAC + 16 + 16;
 
 struct WaveLdsAC {
   uint16_t tile[kTileAC];
-  uint16_t q1[kStrip];
+  uint16_t q1[kStrip / 2 + 64];             // F1 holds at x only if V[x+2] <= V[x+1], at x + 2 only if V[x+1] < V[x+2]: at most 2 of any 4 positions
   uint16_t lut[256];
 };
 
@@ -51,18 +51,34 @@ void scanac2400_kernel (const ScanParams p)
   const uint32_t noise_level = p.noise_level[blk];            // ref: :34-35
 
   // ---- F1: rising edge, quiet two samples later, 6 dB over the noise (ref: :58-75) ----
-  int n1 = 0;
+  // One ballot per 64-position word, kept by the lane of the word's number (nothing is written inside the loop, so the
+  // LDS reads of several words are in flight together); then every lane lists the positions of its own word.
+  // The loop is `for (f1_sample = 1; f1_sample < mlen; ...)`: only positions x of the strip with xlo <= x < xhi count.
+  const uint32_t nl2 = noise_level * 2;
+  u64 mine = 0;
+#pragma unroll 8
   for (int s = 0; s < kWords; s++) {
     const int x = 64 * s + lane;
-    const uint64_t jb = jb0 + x;
-    bool pass = jb >= 1 && jb < mlen;                         // for (f1_sample = 1; f1_sample < mlen; ...)
-    if (pass) {
-      const uint32_t a = V[x - 1], b = V[x], c = V[x + 1], d = V[x + 2];
-      pass = a < b && !(d > b || d > c) && !(noise_level * 2 > (b + c) / 2);
-    }
-    const u64 bm = __ballot (pass);
-    if (pass) w.q1[n1 + __popcll (bm & ((1ull << lane) - 1))] = uint16_t (x);
-    n1 += __popcll (bm);
+    const uint32_t a = V[x - 1], b = V[x], c = V[x + 1], d = V[x + 2];
+    const u64 bm = __ballot (a < b && !(d > b || d > c) && !(nl2 > (b + c) / 2));
+    if (lane == s) mine = bm;
+  }
+  {
+    const long long left = (long long) mlen - (long long) jb0;
+    const int xhi = left >= kStrip ? kStrip : left <= 0 ? 0 : int (left), xlo = jb0 == 0 ? 1 : 0;
+    const int base = 64 * lane;
+    u64 lim = ~0ull;
+    if (lane >= kWords || base >= xhi) lim = 0;
+    else if (base + 64 > xhi) lim = (~0ull) >> (64 - (xhi - base));
+    if (xlo > base) lim &= (~0ull) << (xlo - base);
+    mine &= lim;
+  }
+  const int mycnt = __popcll (mine);
+  const int incl1 = wave_incl_scan (mycnt, lane);
+  const int n1 = __builtin_amdgcn_readlane (incl1, 63);        // <= kStrip / 2 (see q1)
+  {
+    int slot = incl1 - mycnt;
+    for (u64 mm = mine; mm; mm &= mm - 1) w.q1[slot++] = uint16_t (64 * lane + __builtin_ctzll (mm));
   }
   __builtin_amdgcn_s_waitcnt (0xc07f);
   __builtin_amdgcn_wave_barrier ();
