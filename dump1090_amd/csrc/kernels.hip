@@ -13,8 +13,8 @@
 #include "device_common.h"
 #include "kernels.h"
 
-#ifndef SCAN_WAVES
-#define SCAN_WAVES 6
+#ifndef SCANF_WAVES
+#define SCANF_WAVES 5
 #endif
 namespace modes {
 
@@ -28,6 +28,12 @@ namespace modes {
 // byte-table converters run with PAIR = 2, the others with single strips.  kConvUc8LutR8 -- the byte-table instance whose
 // tile holds ranks, one byte per sample (device_common.h) -- has the pair AND the 6 waves: a further 8 % faster.
 template <int CONV> struct ScanPair { static constexpr int n = (CONV == kConvUc8Lut || CONV == kConvUc8LutPower || CONV == kConvUc8LutR8) ? 2 : 1; };
+// Waves per SIMD the register allocation aims for.  With the wave number read as a scalar (below) the integer sc16
+// instance and the rank tile fit 72 registers, and their 21 / 22.6 KB of LDS per workgroup leave room for seven
+// workgroups per CU: 3 % faster than six.  The float converters spill at six already and stay there.
+template <int CONV, bool PE> struct ScanWaves {
+  static constexpr int n = (CONV == kConvSc16Generic || CONV == kConvSc16Q11Generic) ? SCANF_WAVES : (!PE && (CONV == kConvUc8LutR8 || CONV == kConvSc16Int || CONV == kConvMagU16)) ? 7 : 6;
+};
 constexpr int kWavesPerBlock = 4;
 constexpr int kQ1Seg = 256;
 constexpr uint32_t kSynSkipped = 0x80000000u;      // stage D1 did not slice the candidate: the reference never looks at it
@@ -85,7 +91,7 @@ __device__ __forceinline__ uint32_t wave_xor_to63 (uint32_t v)
 // the scan kernel
 // ------------------------------------------------------------------------------------------
 template <int CONV, bool PE>
-__global__ __launch_bounds__ (64 * kWavesPerBlock) __attribute__ ((amdgpu_waves_per_eu (SCAN_WAVES, SCAN_WAVES)))
+__global__ __launch_bounds__ (64 * kWavesPerBlock) __attribute__ ((amdgpu_waves_per_eu (ScanWaves<CONV, PE>::n, ScanWaves<CONV, PE>::n)))
 void scan2400_kernel (const ScanParams p)
 {
   constexpr bool kR8 = CONV == kConvUc8LutR8;       // the tile holds ranks (one byte per sample), not magnitudes
@@ -104,7 +110,7 @@ void scan2400_kernel (const ScanParams p)
   __shared__ uint16_t s_lut[kLut ? 256 : 1];        // as-written uc8 table; rank tile: rank -> magnitude
   __shared__ uint8_t s_rank[kR8 ? 256 : 1];         // rank tile: byte -> rank
   const int lane = lane_id ();
-  const int wv = threadIdx.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane (int (threadIdx.x >> 6));    // wave-uniform: what derives from it is scalar arithmetic
   WaveLds<PE, kPair> &w = lds[wv];
   if (kLut) {
     s_lut[threadIdx.x] = kR8 ? p.rankmag[threadIdx.x] : p.lut256[threadIdx.x];

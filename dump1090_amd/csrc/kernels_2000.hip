@@ -321,7 +321,7 @@ void scan2000_kernel (const ScanParams p)
   __shared__ WaveLds2000<kTile> lds[kWaves2000];
   __shared__ uint32_t crc_tab[256];
   const int lane = lane_id ();
-  const int wv = threadIdx.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane (int (threadIdx.x >> 6));    // wave-uniform: what derives from it is scalar arithmetic
   WaveLds2000<kTile> &w = lds[wv];
   crc_tab[threadIdx.x & 255] = p.crc_table[threadIdx.x & 255];
   __syncthreads ();

@@ -114,7 +114,7 @@ template <int CONV, bool ARRAYS>
 __device__ __forceinline__ void d8_trig_body (const D8Params &q, uint64_t strip_limit, TrigLds *lds)
 {
   const int lane = lane_id ();
-  const int wv = threadIdx.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane (int (threadIdx.x >> 6));    // wave-uniform: what derives from it is scalar arithmetic
   TrigLds &w = lds[wv];
   const uint64_t nstrips = (q.nsteps + kD8StripSteps - 1) / kD8StripSteps;
   const uint64_t strip = uint64_t (blockIdx.x) * kW8 + wv;
@@ -393,7 +393,7 @@ template <int CONV, bool PLAIN, typename Lds>
 __device__ __forceinline__ void d8_window_body (const D8Params &q, Lds *lds, uint32_t *crc_tab)
 {
   const int lane0 = lane_id ();
-  const int wv = threadIdx.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane (int (threadIdx.x >> 6));    // wave-uniform: what derives from it is scalar arithmetic
   WinLds &w = base_of (lds[wv]);
   int32_t *const diff = diffs_of (lds[wv]);
   crc_tab[threadIdx.x & 255] = q.sp.crc_table[threadIdx.x & 255];

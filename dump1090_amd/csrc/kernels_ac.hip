@@ -30,7 +30,7 @@ void scanac2400_kernel (const ScanParams p)
 {
   __shared__ WaveLdsAC lds[kWavesAC];
   const int lane = lane_id ();
-  const int wv = threadIdx.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane (int (threadIdx.x >> 6));    // wave-uniform: what derives from it is scalar arithmetic
   WaveLdsAC &w = lds[wv];
   const uint32_t strip = blockIdx.x * kWavesAC + wv;
   if (strip >= p.nstrips) return;

@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 pat=$1; shift
 d=gpurun_out/pmck; rm -rf $d $d.log
-timeout -s KILL 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAVES SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT -d $d --output-format csv -- python3 bench.py "$@" --no-cpu > $d.log 2>&1 || { echo "pmc FAILED"; tail -3 $d.log; exit 1; }
+timeout -s KILL 150 rocprofv3 --pmc ${PMC_CTRS:-SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAVES SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT} -d $d --output-format csv -- python3 bench.py "$@" --no-cpu > $d.log 2>&1 || { echo "pmc FAILED"; tail -3 $d.log; exit 1; }
 python3 - $d "$pat" <<'PY'
 import sys,glob,csv,collections
 acc=collections.defaultdict(lambda: collections.defaultdict(float)); calls=collections.Counter()
