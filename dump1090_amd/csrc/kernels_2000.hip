@@ -19,16 +19,18 @@ namespace modes {
 
 namespace {
 
-template <int TILE>
+// 7.8 KB per wave without the table: five workgroups of four waves per CU (four with the 8.9 KB of round 1)
+template <int TILE, bool LUT>
 struct WaveLds2000 {
   uint16_t tile[TILE];                      // magnitudes V[P0 - shift ...], shift >= 1
   u64      gt[kPlaneWords2000 + 2];         // bit x: V[P0+x] > V[P0+x+1]
   u64      lt[kPlaneWords2000 + 2];         // bit x: V[P0+x] < V[P0+x+1]
   u64      ev[2][kWords];                   // per position: [0] valid Mode S preamble, [1] Mode A/C reply
-  uint16_t q1[kQ1Cap];                      // positions that pass the adjacent-sample relations
-  uint16_t q2[kQ2Cap2000];                  // event positions: off | vp << 12 | modeA << 13
-  uint16_t lut[256];                        // as-written uc8 table
+  uint16_t q1[kQ1Cap];                      // positions that pass the adjacent-sample relations; stage C is its last reader,
+                                            // after it the first kQ2Cap2000 entries hold the event positions: off | vp << 12 | modeA << 13
+  uint16_t lut[LUT ? 256 : 1];              // as-written uc8 table
 };
+static_assert (kQ2Cap2000 <= kQ1Cap, "the event queue lives in the candidate queue");
 
 constexpr int kWaves2000 = 4;
 
@@ -318,17 +320,19 @@ void scan2000_kernel (const ScanParams p)
 {
   constexpr int kLook = PE ? kLook2000PE : kLook2000;
   constexpr int kTile = kStrip + kLook + kBack2000 + 16;
-  __shared__ WaveLds2000<kTile> lds[kWaves2000];
+  constexpr bool kLut = CONV == kConvUc8Lut || CONV == kConvUc8LutPower;
+  __shared__ WaveLds2000<kTile, kLut> lds[kWaves2000];
   __shared__ uint32_t crc_tab[256];
   const int lane = lane_id ();
   const int wv = __builtin_amdgcn_readfirstlane (int (threadIdx.x >> 6));    // wave-uniform: what derives from it is scalar arithmetic
-  WaveLds2000<kTile> &w = lds[wv];
+  WaveLds2000<kTile, kLut> &w = lds[wv];
+  uint16_t *const q2 = w.q1;
   crc_tab[threadIdx.x & 255] = p.crc_table[threadIdx.x & 255];
   __syncthreads ();
   const uint32_t strip = p.strip_begin + blockIdx.x * kWaves2000 + wv;
   if (strip >= (p.strip_end ? p.strip_end : p.nstrips)) return;
 
-  for (int i = lane; i < 256; i += 64) w.lut[i] = p.lut256 ? p.lut256[i] : uint16_t (0);
+  if (kLut) for (int i = lane; i < 256; i += 64) w.lut[i] = p.lut256 ? p.lut256[i] : uint16_t (0);
   if (lane < kWords) { w.ev[0][lane] = 0; w.ev[1][lane] = 0; }
 
   // ---- stage A: magnitudes of V[P0 - 1 .. P0 + kStrip + kLook] into LDS ----
@@ -433,7 +437,7 @@ void scan2000_kernel (const ScanParams p)
       int slot = inc - c;
       for (u64 mm = both; mm; mm &= mm - 1) {
         const int b = __builtin_ctzll (mm);
-        w.q2[slot++] = uint16_t ((64 * lane + b) | (int ((vpm >> b) & 1) << 12) | (int ((mam >> b) & 1) << 13));
+        q2[slot++] = uint16_t ((64 * lane + b) | (int ((vpm >> b) & 1) << 12) | (int ((mam >> b) & 1) << 13));
       }
     }
   }
@@ -444,49 +448,79 @@ void scan2000_kernel (const ScanParams p)
   //   Mode A/C reply | Mode S slice | retry at the same position | retry behind an accepted, repaired message
   Record *out = p.records + size_t (strip) * p.cap;
   uint32_t nrec = 0;
+  // the Mode A/C reply at an event position (ref: src/demod-2000.c:677-701)
+  auto mode_a_record = [&] (const uint16_t *pp, int off, uint4 *lo, uint4 *hi) {
+    int level = 0;
+    const int code = detect_mode_A_dev (pp, &level);
+    *lo = uint4 { uint32_t (off) | (uint32_t (kKindModeA) << 22) | (32u << 24), uint32_t (kClsModeA), uint32_t (level),
+                  uint32_t ((code >> 8) & 0xFF) | (uint32_t (code & 0xFF) << 8) };
+    *hi = uint4 { 0, 0, 0, 0 };
+  };
+  // the plain slice of a valid preamble, straight from the bit planes (ref: :777-836); returns the slice for the retries
+  auto primary_record = [&] (const uint16_t *pp, int off, uint8_t info, Slice2000 &sl, uint4 *lo, uint4 *hi) {
+    const int s = off + 16, w0 = s >> 6, sh = s & 63;
+    uint32_t M[4], E[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const u64 g = plane_at (w.gt, w0 + k, sh), l = plane_at (w.lt, w0 + k, sh);
+      M[k] = compress_even (g);
+      E[k] = compress_even (~(g | l));
+    }
+    finish_slice (M, E, sl);
+    uint32_t sig = 0, noise = 0;
+    if (sl.msg_len) {                                                 // ref: :777-811
+      sig = uint32_t (pp[0]) + pp[2] + pp[7] + pp[9]; noise = uint32_t (pp[1]) + pp[3] + pp[4] + pp[6] + pp[8];
+      const uint16_t *q = pp + 16;
+      for (int i = 0; i < kShortBits; i++) {
+        const uint32_t a = q[2 * i], b = q[2 * i + 1];
+        sig += a > b ? a : b; noise += a > b ? b : a;
+      }
+    }
+    make_record (p, crc_tab, sl, sig, noise, off, info, lo, hi);
+  };
   for (int base = 0; base < n2 && !overflow; base += 64) {
     const int ci = base + lane;
     const bool act = ci < n2;
+    if constexpr (!PE) {
+      // at most two records per event, and how many is known from the event alone: they go from registers to their slots
+      const uint32_t ev = act ? uint32_t (q2[ci]) : 0u;
+      const int cnt = int (((ev >> 12) & 1u) + ((ev >> 13) & 1u));
+      const int inc = wave_incl_scan (cnt, lane);
+      const uint32_t total = nrec + uint32_t (__builtin_amdgcn_readlane (inc, 63));
+      if (total > p.cap) { overflow = true; break; }
+      uint4 *dst = reinterpret_cast<uint4 *> (out + nrec + (inc - cnt));
+      const int off = ev & 0xFFF;
+      const uint16_t *pp = V + off;
+      if (ev & 0x2000) {
+        uint4 lo, hi;
+        mode_a_record (pp, off, &lo, &hi);
+        if (p.write_records) { dst[0] = lo; dst[1] = hi; }
+        dst += 2;
+      }
+      if (ev & 0x1000) {
+        uint4 lo, hi;
+        Slice2000 sl;
+        primary_record (pp, off, 0, sl, &lo, &hi);
+        if (p.write_records) { dst[0] = lo; dst[1] = hi; }
+      }
+      nrec = total;
+      continue;
+    }
     uint4 lo4[4], hi4[4];
     int cnt = 0;
     if (act) {
-      const uint32_t ev = w.q2[ci];
+      const uint32_t ev = q2[ci];
       const int off = ev & 0xFFF;
       const uint16_t *pp = V + off;
-      if (ev & 0x2000) {                                                  // ref: src/demod-2000.c:677-701
-        int level = 0;
-        const int code = detect_mode_A_dev (pp, &level);
-        lo4[cnt] = uint4 { uint32_t (off) | (uint32_t (kKindModeA) << 22) | (32u << 24), uint32_t (kClsModeA), uint32_t (level),
-                           uint32_t ((code >> 8) & 0xFF) | (uint32_t (code & 0xFF) << 8) };
-        hi4[cnt] = uint4 { 0, 0, 0, 0 };
-        cnt++;
-      }
+      if (ev & 0x2000) { mode_a_record (pp, off, &lo4[cnt], &hi4[cnt]); cnt++; }
       if (ev & 0x1000) {
-        const int s = off + 16, w0 = s >> 6, sh = s & 63;
-        uint32_t M[4], E[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const u64 g = plane_at (w.gt, w0 + k, sh), l = plane_at (w.lt, w0 + k, sh);
-          M[k] = compress_even (g);
-          E[k] = compress_even (~(g | l));
-        }
-        Slice2000 sl;
-        finish_slice (M, E, sl);
-        uint32_t sig = 0, noise = 0;
-        if (sl.msg_len) {                                                 // ref: :777-811
-          sig = uint32_t (pp[0]) + pp[2] + pp[7] + pp[9]; noise = uint32_t (pp[1]) + pp[3] + pp[4] + pp[6] + pp[8];
-          const uint16_t *q = pp + 16;
-          for (int i = 0; i < kShortBits; i++) {
-            const uint32_t a = q[2 * i], b = q[2 * i + 1];
-            sig += a > b ? a : b; noise += a > b ? b : a;
-          }
-        }
         uint8_t info = 0;
         bool oop = false;
         if (PE && p.phase_enhance)                                        // ref: src/demod-2000.c:479-503
           oop = pp[3] > pp[2] / 3 || pp[10] > pp[9] / 3 || pp[6] > pp[7] / 3 || pp[-1] > pp[0] / 3;
         if (oop) info |= kInfoOutOfPhase;
-        make_record (p, crc_tab, sl, sig, noise, off, info, &lo4[cnt], &hi4[cnt]);
+        Slice2000 sl;
+        primary_record (pp, off, info, sl, &lo4[cnt], &hi4[cnt]);
         const uint32_t pinfo = (lo4[cnt].x >> 16) & 0xFF, pnerr = (lo4[cnt].y >> 8) & 0xFF;
         cnt++;
         if (PE && oop) {
