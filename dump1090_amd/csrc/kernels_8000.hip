@@ -19,6 +19,13 @@
 #include "common.h"
 #include "device_common.h"
 
+// waves per SIMD the register allocation of the two big kernels aims for
+#ifndef D8WIN_WAVES
+#define D8WIN_WAVES 7     // 71 registers, nothing spilled; 7 x 22 KB of LDS per CU
+#endif
+#ifndef D8TRIG_WAVES
+#define D8TRIG_WAVES 6
+#endif
 namespace modes {
 
 namespace {
@@ -198,7 +205,7 @@ __device__ __forceinline__ void d8_trig_body (const D8Params &q, uint64_t strip_
 }
 
 template <int CONV>
-__global__ __launch_bounds__ (64 * kW8)
+__global__ __launch_bounds__ (64 * kW8) __attribute__ ((amdgpu_waves_per_eu (D8TRIG_WAVES, D8TRIG_WAVES)))
 void d8_trig_kernel (const D8Params q, uint64_t strip_limit)
 {
   __shared__ TrigLds lds[kW8];
@@ -614,7 +621,7 @@ __device__ __forceinline__ void d8_window_body (const D8Params &q, Lds *lds, uin
 }
 
 template <int CONV>
-__global__ __launch_bounds__ (64 * kW8) __attribute__ ((amdgpu_waves_per_eu (6, 6)))     // 80 registers, nothing spilled
+__global__ __launch_bounds__ (64 * kW8) __attribute__ ((amdgpu_waves_per_eu (D8WIN_WAVES, D8WIN_WAVES)))
 void d8_window_kernel (const D8Params q)
 {
   __shared__ WinLds lds[kW8];
