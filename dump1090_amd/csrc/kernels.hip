@@ -732,6 +732,23 @@ void accept_kernel (const AcceptParams p)
   if (p.dirty && !p.dirty[blk]) return;                      // same entry cache as in the round before: same results
   __builtin_amdgcn_s_setprio (3);                            // the pass is latency bound and often shares the GPU with a scan
   AcceptLds &w = lds[wv];
+  const uint32_t first_strip = blk * p.strips_per_block;
+  const uint32_t last_strip = min (first_strip + p.strips_per_block, p.nstrips);
+  // the block's records: counts of its strips (<= 64 of them)
+  const uint32_t nst = last_strip - first_strip;
+  const uint32_t my_count = uint32_t (lane) < nst ? clean_count (p.counts[first_strip + lane]) : 0u;
+  const uint32_t my_incl = uint32_t (wave_incl_scan (int (my_count), lane));
+  const uint32_t total = uint32_t (__builtin_amdgcn_readlane (int (my_incl), 63));
+  if (total == 0) {
+    // nothing to walk (most blocks of a quiet recording): the block accepts nothing and writes no slot; the 4 KB of its
+    // entry cache are not even fetched
+    if (uint32_t (lane) < nst && p.acc_counts[first_strip + lane] != 0) p.acc_counts[first_strip + lane] = 0;
+    const bool prev = !p.first_round && p.blk_wrote[blk] != 0;
+    if (lane == 0 && (p.first_round || prev)) p.blk_wrote[blk] = 0;
+    if (lane == 0 && prev) atomicOr (p.changed, 1u);
+    if (lane < kBlkStats) p.blk_stats[size_t (blk) * kBlkStats + lane] = 0;
+    return;
+  }
   const uint32_t *entry = p.first_round ? p.cache_in : p.snap_in + size_t (blk) * kIcaoSlots;     // the cache as the block starts with it
   for (int i = lane; i < int (kIcaoSlots); i += 64) w.cache[i] = entry[i];
   if (lane < int (kIcaoSlots / 32)) w.written[lane] = 0;
@@ -739,23 +756,14 @@ void accept_kernel (const AcceptParams p)
   __builtin_amdgcn_s_waitcnt (0xc07f);
   __builtin_amdgcn_wave_barrier ();
 
-  const uint32_t first_strip = blk * p.strips_per_block;
-  const uint32_t last_strip = min (first_strip + p.strips_per_block, p.nstrips);
   const uint64_t blk_pos0 = uint64_t (blk) * p.block_samples;
   const uint32_t blk_len = uint32_t (min (uint64_t (p.block_samples), p.nsamples - blk_pos0));
   uint32_t skip_until = 0;                                   // each demod_2400 call starts at j = 0
   uint32_t st_demod = 0, st_oop = 0, st_good = 0, st_bad = 0, st_fix1 = 0, st_fix2 = 0, st_unk = 0, st_vp = 0, st_modeac = 0;
 
-  // the block's records, 64 at a time across its strips: counts -> exclusive prefix in LDS, record g -> (strip, index)
-  const uint32_t nst = last_strip - first_strip;                        // <= 64
-  uint32_t total;
-  {
-    const uint32_t c = uint32_t (lane) < nst ? clean_count (p.counts[first_strip + lane]) : 0u;
-    const uint32_t incl = uint32_t (wave_incl_scan (int (c), lane));
-    w.prefix[lane] = incl - c;
-    w.accn[lane] = 0;
-    total = uint32_t (__builtin_amdgcn_readlane (int (incl), 63));
-  }
+  // the block's records, 64 at a time across its strips: exclusive prefix of the counts in LDS, record g -> (strip, index)
+  w.prefix[lane] = my_incl - my_count;
+  w.accn[lane] = 0;
   __builtin_amdgcn_s_waitcnt (0xc07f);
   __builtin_amdgcn_wave_barrier ();
   // A block whose entry cache changed repeats itself all the same unless the change shows where a record looks: every
