@@ -30,7 +30,10 @@ namespace modes {
 
 namespace {
 
-constexpr int kW8 = 4;                                           // waves per workgroup
+#ifndef D8_WG_WAVES
+#define D8_WG_WAVES 4
+#endif
+constexpr int kW8 = D8_WG_WAVES;                                           // waves per workgroup
 constexpr int kTrigRows = kD8StripSteps + 56;                    // 312 rows of 8 differences per strip
 constexpr int kTrigTile = 2520;                                  // 8 * 312 + 4 + 15 alignment, rounded to 8
 constexpr int kWinRows = 241;                                    // rows s-4 .. s+236 of a window
