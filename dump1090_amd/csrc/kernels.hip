@@ -32,7 +32,9 @@ template <int CONV> struct ScanPair { static constexpr int n = (CONV == kConvUc8
 // instance and the rank tile fit 72 registers, and their 21 / 22.6 KB of LDS per workgroup leave room for seven
 // workgroups per CU: 3 % faster than six.  The float converters spill at six already and stay there.
 template <int CONV, bool PE> struct ScanWaves {
-  static constexpr int n = (CONV == kConvSc16Generic || CONV == kConvSc16Q11Generic) ? SCANF_WAVES : (!PE && (CONV == kConvUc8LutR8 || CONV == kConvSc16Int || CONV == kConvMagU16)) ? 7 : 6;
+  static constexpr int n = (CONV == kConvSc16Generic || CONV == kConvSc16Q11Generic) ? SCANF_WAVES :
+                           (!PE && (CONV == kConvUc8Lut || CONV == kConvUc8LutPower)) ? 4 :       // two strips of magnitudes per wave: 39 KB of LDS per workgroup
+                           (!PE && (CONV == kConvUc8LutR8 || CONV == kConvSc16Int || CONV == kConvMagU16)) ? 7 : 6;
 };
 constexpr int kWavesPerBlock = 4;
 constexpr int kQ1Seg = 256;
