@@ -1142,21 +1142,85 @@ void emit2400_kernel (const EmitParams p)
   const Record *recs = p.records + size_t (strip) * p.cap;
   const uint32_t nrec = p.counts[strip];
   constexpr int bps = (CONV == kConvUc8Generic || CONV == kConvMagU16) ? 2 : 4;      // bytes per sample where the fast path applies
+  // one accepted record -> one message (ref: src/demod-2400.c:463-497, src/demod-2000.c:960-966); `acc` = the sum of
+  // squares behind the signal level, `slot` = where the message goes in the strip's part of the list
+  auto build = [&] (uint32_t d0, uint32_t d1, uint32_t crc, uint32_t d3, uint32_t d4, uint32_t d5, uint32_t d6, uint32_t d7,
+                    u64 acc, uint32_t slot) {
+    const uint32_t off = d0 & 0xFFFF, phase = (d0 >> 16) & 0xFF, df = d0 >> 24;
+    const uint32_t cls = d1 & 0xFF, nerr = (d1 >> 8) & 0xFF, bit0 = (d1 >> 16) & 0xFF, bit1 = d1 >> 24;
+    u64 mlo = (u64 (d4) << 32) | d3, mhi = (u64 (d6 & 0xFFFF) << 32) | d5;           // msg[0..7], msg[8..13]
+    const int16_t score = int16_t ((d6 >> 24) | ((d7 & 0xFF) << 8));                   // pad[0..1]
+    const uint64_t P = uint64_t (strip) * kStrip + off;
+    const int mbits = msg_bits_for_df (int (df));
+    const int slen = mbits * 12 / 5;
+    const uint64_t blk = P / p.block_samples, j = P % p.block_samples;
+    const uint64_t counter = p.first_sample + blk * p.block_samples;
+    const uint64_t block_ts = uint64_t ((double (counter) * 12E6) / double (p.sample_rate));        // ref: src/infile.c:143
+    uint64_t ts = p.mode == 2000 ? block_ts + j * 6                                                  // ref: src/demod-2000.c:960
+                                 : block_ts + j * 5 + phase;                                         // ref: src/demod-2400.c:467
+    const bool ap = cls == kClsAP || cls == kClsAP2, acq = cls == kClsDF11;
+    uint32_t msg_bits, msg_type, addr, ocrc = 0, eb = 0, oph = 0;
+    int16_t oscore;
+    double sig;
+    if (cls == kClsModeA) {                     // ref: src/demod-2000.c:318,677-701, src/dump1090.c:2722-2766
+      const uint32_t code = ((d3 & 0xFF) << 8) | ((d3 >> 8) & 0xFF);
+      ts = block_ts + (j + 1) * 6;
+      msg_bits = 16; msg_type = 32;
+      addr = (code & 0x0000FF7Fu) | kNonIcao;
+      oscore = -1;
+      const int lv = int (crc);
+      sig = double (int (uint32_t (lv) * uint32_t (lv))) / (65535.0 * 65535.0);   // int product as the reference forms it
+    } else {
+      if (acq && (crc & 0xFFFF80u)) eb = nerr;
+      if (!ap && !acq && crc) eb = nerr;
+      if (eb >= 1) { const uint32_t b = bit0 >> 3; const u64 f = u64 (0x80u >> (bit0 & 7)); if (b < 8) mlo ^= f << (8 * b); else mhi ^= f << (8 * (b - 8)); }
+      if (eb >= 2) { const uint32_t b = bit1 >> 3; const u64 f = u64 (0x80u >> (bit1 & 7)); if (b < 8) mlo ^= f << (8 * b); else mhi ^= f << (8 * (b - 8)); }
+      const uint32_t aa = (uint32_t (mlo >> 8) & 0xFF) << 16 | (uint32_t (mlo >> 16) & 0xFF) << 8 | (uint32_t (mlo >> 24) & 0xFF);
+      msg_bits = uint32_t (mbits);
+      msg_type = df >= 24 ? 24 : df;
+      addr = ap ? crc : acq ? aa : (aa | non_icao_flag_words (mlo, mhi, int (df)));
+      ocrc = crc;
+      oscore = score;
+      oph = p.mode == 2000 ? 0u : phase;
+      // demod_2000's sig_level is wiped by decode_mode_S_message's memset (ref: src/demod-2000.c:966, src/dump1090.c:2385)
+      sig = p.mode == 2000 ? 0.0 : (double (acc) / 65535.0 / 65535.0) / double (slen);
+    }
+    const u64 sigbits = u64 (__double_as_longlong (sig));
+    uint4 o0, o1, o2; uint2 o3;
+    o0.x = uint32_t (ts); o0.y = uint32_t (ts >> 32); o0.z = uint32_t (mlo); o0.w = uint32_t (mlo >> 32);
+    o1.x = uint32_t (mhi); o1.y = (uint32_t (mhi >> 32) & 0xFFFFu) | (msg_bits << 16) | (msg_type << 24); o1.z = addr; o1.w = ocrc;
+    o2.x = uint32_t (uint16_t (oscore)) | (eb << 16) | (oph << 24); o2.y = uint32_t (p.first_sample / p.block_samples + blk);
+    o2.z = uint32_t (sigbits); o2.w = uint32_t (sigbits >> 32);
+    o3.x = uint32_t (j); o3.y = 0;
+    uint32_t *dst = reinterpret_cast<uint32_t *> (out + slot);
+    *reinterpret_cast<uint2 *> (dst) = make_uint2 (o0.x, o0.y);
+    *reinterpret_cast<uint2 *> (dst + 2) = make_uint2 (o0.z, o0.w);
+    *reinterpret_cast<uint2 *> (dst + 4) = make_uint2 (o1.x, o1.y);
+    *reinterpret_cast<uint2 *> (dst + 6) = make_uint2 (o1.z, o1.w);
+    *reinterpret_cast<uint2 *> (dst + 8) = make_uint2 (o2.x, o2.y);
+    *reinterpret_cast<uint2 *> (dst + 10) = make_uint2 (o2.z, o2.w);
+    *reinterpret_cast<uint2 *> (dst + 12) = o3;
+  };
   uint32_t k = 0;
   for (uint32_t rb = 0; rb < nrec && k < nacc; rb += 64) {
     uint4 ra = { 0, 0, 0, 0 }, rc = { 0, 0, 0, 0 };
     if (rb + lane < nrec) { const uint4 *s4 = reinterpret_cast<const uint4 *> (recs + rb + lane); ra = s4[0]; rc = s4[1]; }
+    if (p.mode == 2000) {
+      // demod_2000's messages carry no measured level (decode_mode_S_message's memset wipes it): nothing is summed, so
+      // every accepted record of the batch becomes its message in its own lane
+      const bool mine = (rc.z >> 16) & 1u;
+      const u64 accm = __ballot (mine);
+      if (mine) build (ra.x, ra.y, ra.z, ra.w, rc.x, rc.y, rc.z, rc.w, 0, k + uint32_t (__popcll (accm & ((1ull << lane) - 1))));
+      k += uint32_t (__popcll (accm));
+      continue;
+    }
     for (u64 accm = __ballot ((rc.z >> 16) & 1u); accm; accm &= accm - 1, k++) {        // flags bit 0
       const int src = __builtin_ctzll (accm);
       const uint32_t d0 = bcast (ra.x, src), d1 = bcast (ra.y, src), crc = bcast (ra.z, src), d3 = bcast (ra.w, src);
       const uint32_t d4 = bcast (rc.x, src), d5 = bcast (rc.y, src), d6 = bcast (rc.z, src), d7 = bcast (rc.w, src);
-      const uint32_t off = d0 & 0xFFFF, phase = (d0 >> 16) & 0xFF, df = d0 >> 24;
-      const uint32_t cls = d1 & 0xFF, nerr = (d1 >> 8) & 0xFF, bit0 = (d1 >> 16) & 0xFF, bit1 = d1 >> 24;
-      u64 mlo = (u64 (d4) << 32) | d3, mhi = (u64 (d6 & 0xFFFF) << 32) | d5;           // msg[0..7], msg[8..13]
-      const int16_t score = int16_t ((d6 >> 24) | ((d7 & 0xFF) << 8));                   // pad[0..1]
+      const uint32_t off = d0 & 0xFFFF, df = d0 >> 24;
       const uint64_t P = uint64_t (strip) * kStrip + off;
-      const int mbits = msg_bits_for_df (int (df));
-      const int slen = mbits * 12 / 5;
+      const int slen = msg_bits_for_df (int (df)) * 12 / 5;
       u64 acc = 0;                                  // ref: src/demod-2400.c:486-497
       if (p.mode != 2000) {
         const long long n0 = (long long) P + 19 - (long long) p.ov;                     // first sample of the sum
@@ -1201,55 +1265,7 @@ void emit2400_kernel (const EmitParams p)
         }
       }
       for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor (acc, d, 64);
-      if (lane == 0) {
-        const uint64_t blk = P / p.block_samples, j = P % p.block_samples;
-        const uint64_t counter = p.first_sample + blk * p.block_samples;
-        const uint64_t block_ts = uint64_t ((double (counter) * 12E6) / double (p.sample_rate));        // ref: src/infile.c:143
-        uint64_t ts = p.mode == 2000 ? block_ts + j * 6                                                  // ref: src/demod-2000.c:960
-                                     : block_ts + j * 5 + phase;                                         // ref: src/demod-2400.c:467
-        const bool ap = cls == kClsAP || cls == kClsAP2, acq = cls == kClsDF11;
-        uint32_t msg_bits, msg_type, addr, ocrc = 0, eb = 0, oph = 0;
-        int16_t oscore;
-        double sig;
-        if (cls == kClsModeA) {                     // ref: src/demod-2000.c:318,677-701, src/dump1090.c:2722-2766
-          const uint32_t code = ((d3 & 0xFF) << 8) | ((d3 >> 8) & 0xFF);
-          ts = block_ts + (j + 1) * 6;
-          msg_bits = 16; msg_type = 32;
-          addr = (code & 0x0000FF7Fu) | kNonIcao;
-          oscore = -1;
-          const int lv = int (crc);
-          sig = double (int (uint32_t (lv) * uint32_t (lv))) / (65535.0 * 65535.0);   // int product as the reference forms it
-        } else {
-          if (acq && (crc & 0xFFFF80u)) eb = nerr;
-          if (!ap && !acq && crc) eb = nerr;
-          if (eb >= 1) { const uint32_t b = bit0 >> 3; const u64 f = u64 (0x80u >> (bit0 & 7)); if (b < 8) mlo ^= f << (8 * b); else mhi ^= f << (8 * (b - 8)); }
-          if (eb >= 2) { const uint32_t b = bit1 >> 3; const u64 f = u64 (0x80u >> (bit1 & 7)); if (b < 8) mlo ^= f << (8 * b); else mhi ^= f << (8 * (b - 8)); }
-          const uint32_t aa = (uint32_t (mlo >> 8) & 0xFF) << 16 | (uint32_t (mlo >> 16) & 0xFF) << 8 | (uint32_t (mlo >> 24) & 0xFF);
-          msg_bits = uint32_t (mbits);
-          msg_type = df >= 24 ? 24 : df;
-          addr = ap ? crc : acq ? aa : (aa | non_icao_flag_words (mlo, mhi, int (df)));
-          ocrc = crc;
-          oscore = score;
-          oph = p.mode == 2000 ? 0u : phase;
-          // demod_2000's sig_level is wiped by decode_mode_S_message's memset (ref: src/demod-2000.c:966, src/dump1090.c:2385)
-          sig = p.mode == 2000 ? 0.0 : (double (acc) / 65535.0 / 65535.0) / double (slen);
-        }
-        const u64 sigbits = u64 (__double_as_longlong (sig));
-        uint4 o0, o1, o2; uint2 o3;
-        o0.x = uint32_t (ts); o0.y = uint32_t (ts >> 32); o0.z = uint32_t (mlo); o0.w = uint32_t (mlo >> 32);
-        o1.x = uint32_t (mhi); o1.y = (uint32_t (mhi >> 32) & 0xFFFFu) | (msg_bits << 16) | (msg_type << 24); o1.z = addr; o1.w = ocrc;
-        o2.x = uint32_t (uint16_t (oscore)) | (eb << 16) | (oph << 24); o2.y = uint32_t (p.first_sample / p.block_samples + blk);
-        o2.z = uint32_t (sigbits); o2.w = uint32_t (sigbits >> 32);
-        o3.x = uint32_t (j); o3.y = 0;
-        uint32_t *dst = reinterpret_cast<uint32_t *> (out + k);
-        *reinterpret_cast<uint2 *> (dst) = make_uint2 (o0.x, o0.y);
-        *reinterpret_cast<uint2 *> (dst + 2) = make_uint2 (o0.z, o0.w);
-        *reinterpret_cast<uint2 *> (dst + 4) = make_uint2 (o1.x, o1.y);
-        *reinterpret_cast<uint2 *> (dst + 6) = make_uint2 (o1.z, o1.w);
-        *reinterpret_cast<uint2 *> (dst + 8) = make_uint2 (o2.x, o2.y);
-        *reinterpret_cast<uint2 *> (dst + 10) = make_uint2 (o2.z, o2.w);
-        *reinterpret_cast<uint2 *> (dst + 12) = o3;
-      }
+      if (lane == 0) build (d0, d1, crc, d3, d4, d5, d6, d7, acc, k);
     }
   }
   }
