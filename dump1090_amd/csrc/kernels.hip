@@ -155,14 +155,29 @@ void scan2400_kernel (const ScanParams p)
       const uint4 *vw = reinterpret_cast<const uint4 *> (Vh.p + 32 * lane);
       const uint4 x0 = vw[0], x1 = vw[1];
       const uint32_t wd[9] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, Vh.ord (32 * lane + 32) };
+      // Four neighbour pairs are compared per word: with H = 0x80 and L = 0x7F in every byte, (x | H) - (y & L) never
+      // borrows between bytes and keeps bit 7 where the low seven bits of x are >= those of y; the top bits decide
+      // otherwise.  v_dot4 with (1, 2, 4, 8) / (16, 32, 64, 128) then packs the four verdicts of a word next to those
+      // of its neighbour: 3.75 operations per position instead of 5 with one subtraction per pair.
+      const uint32_t H = 0x80808080u, L = 0x7F7F7F7Fu;
+      uint32_t l7[4], g7[4];
 #pragma unroll
-      for (int k = 31; k >= 0; k--) {
-        const int a = int ((wd[k >> 2] >> (8 * (k & 3))) & 0xFFu);
-        const int b = int ((wd[(k + 1) >> 2] >> (8 * ((k + 1) & 3))) & 0xFFu);
-        const int d = a - b;
-        LT = alignbit (LT, uint32_t (d), 31);        // shifts in (a < b)
-        GT = alignbit (GT, uint32_t (-d), 31);       // shifts in (a > b)
+      for (int i = 0; i < 4; i++) {
+        uint32_t al = 0, ag = 0;
+#pragma unroll
+        for (int h = 1; h >= 0; h--) {
+          const uint32_t x = wd[2 * i + h], y = __builtin_amdgcn_alignbyte (wd[2 * i + h + 1], x, 1);   // the four samples one further on
+          const uint32_t t1 = (x | H) - (y & L), t2 = (y | H) - (x & L);
+          const uint32_t ltw = ((~x & y) | (~(x ^ y) & ~t1)) & H;                                         // bit 7 of a byte: x < y
+          const uint32_t gtw = ((~y & x) | (~(x ^ y) & ~t2)) & H;                                         //                  x > y
+          const uint32_t K = h ? 0x80402010u : 0x08040201u;
+          al = __builtin_amdgcn_udot4 (ltw, K, al, false);
+          ag = __builtin_amdgcn_udot4 (gtw, K, ag, false);
+        }
+        l7[i] = al; g7[i] = ag;                                                                           // eight verdicts, times 128
       }
+      LT = (l7[0] >> 7) | (l7[1] << 1) | (l7[2] << 9) | (l7[3] << 17);
+      GT = (g7[0] >> 7) | (g7[1] << 1) | (g7[2] << 9) | (g7[3] << 17);
     } else {
       const uint4 *vw = reinterpret_cast<const uint4 *> (Vh.p + 32 * lane);
       const uint4 x0 = vw[0], x1 = vw[1], x2 = vw[2], x3 = vw[3];
