@@ -375,8 +375,8 @@ def run_workload(name, args, world, rank, local, dev, want_cpu):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--gib", type=float, default=4.0, help="IQ bytes per GPU, GiB")
     ap.add_argument("--workload", default="uc8_2400", choices=sorted(WORKLOADS))
     ap.add_argument("--converter", default="reference", choices=["reference", "power"],
