@@ -193,6 +193,21 @@ struct modes_engine {
   PinBuf<uint64_t> pin_rpos;                  // 8 MS/s: positions and lengths of the messages to measure, staged for the device
   PinBuf<uint32_t> pin_rlen;
   std::vector<uint32_t> d8_lvl_msg;           // 8 MS/s: which message each measured level belongs to
+  // 8 MS/s: how the last completed run went, range by range -- the ICAO cache, the messages and the counters behind each
+  // range.  A run over the same windows (a hand-over round in which only the entry cache moved) stops walking at the
+  // first range boundary where its cache is the last run's: from there on it would repeat that run step for step.
+  struct D8Trace {
+    bool valid = false;
+    std::vector<uint32_t> lo;                               // the ranges of chunks
+    std::vector<uint32_t> cache_after;                      // [range][kIcaoSlots]
+    std::vector<size_t> msg_end;                            // messages behind each range
+    std::vector<Pass8000Stats> ps_after;
+    std::vector<uint64_t> cand_after;
+    std::vector<uint32_t> final_cache;
+    uint64_t serial = 0;                                    // which message list is this run's
+  } d8_trace;
+  std::vector<modes_message> d8_prev_msgs;    // the message list of the run before (swapped out of `messages` when a run starts)
+  uint64_t d8_msgs_serial = 0, d8_prev_serial = 0, d8_serials = 0;   // 0: not the list of a traced run
   PinBuf<uint64_t> pin_sums, pin_tot;         // pin_tot: four totals per range of chunks, written by the device
   DevBuf<uint64_t> d8_tot;
   PinBuf<D8Window> pin_wins2;                 // a range that outgrew its share of pin_wins / pin_recs
@@ -1194,6 +1209,9 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   auto since_entry = [&] { return std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - t_entry).count (); };
   const bool timing = getenv ("MODES_TIMING") != nullptr;
   HIP_TRY (hipSetDevice (e->cfg.device));
+  e->d8_prev_msgs.swap (e->messages);
+  e->d8_prev_serial = e->d8_msgs_serial;
+  e->d8_msgs_serial = 0;
   e->messages.clear ();
   e->in_pinned = false; e->pin_n = 0;
   memset (&e->stats, 0, sizeof e->stats);
@@ -1483,7 +1501,49 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   double host_ms = 0.0;
   e->kernel_ms[0] = 0;
   e->messages.reserve (e->d8_last_msgs + e->d8_last_msgs / 8 + 64);
+  // the last run's trace, if this run walks the same windows in the same ranges; the trace of this run
+  modes_engine::D8Trace prev;
+  prev.valid = false;
+  if (same_windows && e->d8_trace.valid && e->d8_trace.lo == lo && e->d8_trace.serial && e->d8_trace.serial == e->d8_prev_serial &&
+      !getenv ("MODES_D8_NO_EARLY_STOP"))
+    prev = std::move (e->d8_trace);
+  e->d8_trace = modes_engine::D8Trace ();
+  modes_engine::D8Trace cur;
+  cur.lo = lo;
+  cur.cache_after.resize (size_t (nranges) * kIcaoSlots); cur.msg_end.resize (nranges); cur.ps_after.resize (nranges); cur.cand_after.resize (nranges);
+  auto ps_add = [] (Pass8000Stats a, const Pass8000Stats &b, const Pass8000Stats &c) {     // a + b - c
+    static_assert (sizeof (Pass8000Stats) % sizeof (uint64_t) == 0, "counters only");
+    uint64_t *x = reinterpret_cast<uint64_t *> (&a);
+    const uint64_t *y = reinterpret_cast<const uint64_t *> (&b), *z = reinterpret_cast<const uint64_t *> (&c);
+    for (size_t i = 0; i < sizeof (Pass8000Stats) / sizeof (uint64_t); i++) x[i] += y[i] - z[i];
+    return a;
+  };
+  bool stopped_early = false;
   for (uint32_t r = 0; r < nranges; r++) {
+    if (r) {
+      // behind range r - 1: the trace, and -- over the same windows as the last run -- whether the two runs have met
+      const uint32_t d = r - 1;
+      memcpy (cur.cache_after.data () + size_t (d) * kIcaoSlots, e->cache.raw (), kIcaoSlots * sizeof (uint32_t));
+      cur.msg_end[d] = e->messages.size (); cur.ps_after[d] = ps; cur.cand_after[d] = e->stats.candidates;
+      if (prev.valid && !memcmp (prev.cache_after.data () + size_t (d) * kIcaoSlots, e->cache.raw (), kIcaoSlots * sizeof (uint32_t))) {
+        // same cache, same windows, and every record this run keeps that the last one dropped asks for an address the
+        // cache does not hold: ranges r .. end go as they went.  (The device finishes their count / gather unobserved.)
+        const size_t n_now = e->messages.size (), p_from = prev.msg_end[d];
+        e->messages.insert (e->messages.end (), e->d8_prev_msgs.begin () + p_from, e->d8_prev_msgs.end ());
+        for (uint32_t k = r; k < nranges; k++) {
+          memcpy (cur.cache_after.data () + size_t (k) * kIcaoSlots, prev.cache_after.data () + size_t (k) * kIcaoSlots, kIcaoSlots * sizeof (uint32_t));
+          cur.msg_end[k] = prev.msg_end[k] - p_from + n_now;
+          cur.ps_after[k] = ps_add (ps, prev.ps_after[k], prev.ps_after[d]);
+          cur.cand_after[k] = e->stats.candidates + prev.cand_after[k] - prev.cand_after[d];
+        }
+        ps = cur.ps_after[nranges - 1];
+        e->stats.candidates = cur.cand_after[nranges - 1];
+        memcpy (e->cache.raw (), prev.final_cache.data (), kIcaoSlots * sizeof (uint32_t));
+        e->stats.replay_rounds = r;                             // ranges walked before the runs met
+        stopped_early = true;
+        break;
+      }
+    }
     const uint32_t c0 = lo[r], c1 = lo[r + 1];
     const auto t_wait0 = std::chrono::steady_clock::now ();
     HIP_TRY (hipEventSynchronize (e->d8_gathered[r]));
@@ -1557,14 +1617,24 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
     const auto t_lvl0 = t_host0;
     if (timing) fprintf (stderr, ", levels queued in %.3f ms\n", std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - t_lvl0).count ());
   }
+  if (!stopped_early) {
+    const uint32_t d = nranges - 1;
+    memcpy (cur.cache_after.data () + size_t (d) * kIcaoSlots, e->cache.raw (), kIcaoSlots * sizeof (uint32_t));
+    cur.msg_end[d] = e->messages.size (); cur.ps_after[d] = ps; cur.cand_after[d] = e->stats.candidates;
+  }
   const auto t_end0 = std::chrono::steady_clock::now ();
   HIP_TRY (hipStreamSynchronize (lvl));
   HIP_TRY (hipStreamSynchronize (stream));
   if (timing) fprintf (stderr, "  %.3f ms: end: %.3f ms for the streams to drain\n", since_entry (), std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - t_end0).count ());
   e->d8_win_gen = e->d8_planes_gen; e->d8_win_pending = (long long) q.pending; e->d8_win_tail = trig_tail_in;
-  e->d8_last_chunks = nchunks; e->d8_last_nwin = all_win; e->d8_last_nrec = all_rec; e->d8_last_msgs = e->messages.size ();
+  if (!stopped_early) { e->d8_last_chunks = nchunks; e->d8_last_nwin = all_win; e->d8_last_nrec = all_rec; }   // (what sizes the next run's arrays)
+  e->d8_last_msgs = e->messages.size ();
   for (size_t i = 0; i < nsums; i++)
     e->messages[lvl_msg[i]].sig_level = (double (e->pin_sums.p[i]) / 65535.0 / 65535.0) / double (e->pin_rlen.p[i]);
+  cur.final_cache.assign (e->cache.raw (), e->cache.raw () + kIcaoSlots);
+  cur.serial = e->d8_msgs_serial = ++e->d8_serials;
+  cur.valid = true;
+  e->d8_trace = std::move (cur);
   {
     // the hand-over state (the copies were queued in front of the first range: long done)
     modes_d8_state &o = e->d8_out;

@@ -175,7 +175,7 @@ typedef struct modes_stats {
   uint64_t CRC_good, CRC_bad, CRC_fixed, CRC_single_bit_fix, CRC_two_bits_fix;
   uint64_t demod_rejected_unknown;
   uint64_t candidates;       /* records that left the scan kernel               */
-  uint64_t replay_rounds;    /* fixed-point rounds of the device replay          */
+  uint64_t replay_rounds;    /* fixed-point rounds of the device replay; 8 MS/s: ranges walked before a run met the one before (0: walked all) */
   uint64_t scan_retries;     /* scans repeated with more candidate slots per strip */
 } modes_stats;
 

@@ -114,3 +114,57 @@ def test_range_that_outgrows_its_pinned_share_is_gathered_again():
     e.run_host(iq)
     assert e.stats()["scan_retries"] == 0
     assert_same_messages(e.messages(), exp)
+
+
+def test_round_over_the_same_windows_stops_where_it_meets_the_round_before(monkeypatch):
+    """A hand-over round of a sharded decode runs over the same windows with another entry cache.  It walks the ranges of
+    chunks until its cache is the one the round before had at the same boundary, and takes the rest from that round:
+    same messages, statistics and final cache as the complete walk, in fewer ranges (stats.replay_rounds)."""
+    import torch
+    from dump1090_amd import synth_torch
+    n = 17 * 65536 * 8 + 4321                                     # 17+ chunks: four ranges
+    d, _ = synth_torch.capture_gpu(n, 8.0e6, "sc16", seed=93, frames_per_sec=2500, device="cuda:0", n_icao=8, n_bank=512)
+    torch.cuda.synchronize()
+    nbytes = d.numel() * d.element_size()
+    # an entry cache as a shard before this one would leave it: some of the aircraft known, some not
+    first = da.Engine(8000000, da.INPUT_SC16, fix_bits=1)
+    first.run_device(d.data_ptr(), nbytes // 8 // 16 * 16)
+    entry = first.get_icao()
+    assert np.count_nonzero(entry) >= 3
+
+    def rounds(early):
+        if early:
+            monkeypatch.delenv("MODES_D8_NO_EARLY_STOP", raising=False)
+        else:
+            monkeypatch.setenv("MODES_D8_NO_EARLY_STOP", "1")
+        e = da.Engine(8000000, da.INPUT_SC16, fix_bits=1)
+        e.set_icao(None)
+        e.run_device(d.data_ptr(), nbytes)                        # round one: cold cache
+        cold = e.messages().copy()
+        out = []
+        for cache in (entry, entry, None):                        # a changed entry, the same again, back to cold
+            e.set_icao(cache)
+            e.d8_reuse_planes()
+            e.run_device(d.data_ptr(), nbytes)
+            out.append((e.messages().copy(), dict(e.stats()), e.get_icao().copy()))
+        return cold, out
+
+    cold_a, full = rounds(False)
+    cold_b, fast = rounds(True)
+    assert_same_messages(cold_a, cold_b)
+    assert len(cold_a) > 1000
+    assert len(full[0][0]) != len(cold_a) or not np.array_equal(full[0][0]["score"], cold_a["score"])   # the entry cache matters
+    for (m0, s0, c0), (m1, s1, c1) in zip(full, fast):
+        assert_same_messages(m1, m0)
+        np.testing.assert_array_equal(m1["sig_level"], m0["sig_level"])
+        np.testing.assert_array_equal(c1, c0)
+        for k in STAT_KEYS:
+            assert s1[k] == s0[k], k
+    assert all(s["replay_rounds"] == 0 for _, s, _ in full)
+    assert 1 <= fast[0][1]["replay_rounds"] <= 3                  # met the cold round inside the four ranges
+    assert fast[1][1]["replay_rounds"] == 1                       # the same entry again: met behind the first range
+    # and the whole thing is what a fresh engine makes of that entry cache
+    ref = da.Engine(8000000, da.INPUT_SC16, fix_bits=1)
+    ref.set_icao(entry)
+    ref.run_device(d.data_ptr(), nbytes)
+    assert_same_messages(fast[0][0], ref.messages())
