@@ -21,6 +21,9 @@ class IcaoCache {
   static uint32_t hash (uint32_t a);
   void add (uint32_t a) { slot_[hash (a)] = a; }
   bool test (uint32_t a) const { uint32_t s = slot_[hash (a)]; return s && s == a; }
+  // the same with the slot found once
+  bool test_at (uint32_t slot, uint32_t a) const { uint32_t s = slot_[slot]; return s && s == a; }
+  void add_at (uint32_t slot, uint32_t a) { slot_[slot] = a; }
   uint32_t *raw () { return slot_; }
   const uint32_t *raw () const { return slot_; }
  private:
@@ -147,6 +150,57 @@ inline int accept_record (const Record &r, IcaoCache &cache, modes_message *out)
   return 0;
 }
 
+// score_record () and accept_record () for a window's ONLY candidate (demod_8000's usual window), in one go: both ask the
+// cache about the same address, so its slot is found and read once.  Returns the score (< 0: nothing is decoded, `out`
+// is scratch); *rc = what accept_record () would have returned.  Same rules, same order of cache reads and writes.
+inline int score_and_accept (const Record &r, IcaoCache &cache, modes_message *out, int *rc)
+{
+  uint8_t *msg = out->msg;
+  memcpy (msg, r.msg, kLongBytes);
+  out->msg_type = r.df;
+  out->msg_bits = uint8_t (len_by_type (r.df));
+  out->crc = r.crc;
+  out->error_bits = 0;
+  out->addr = 0;
+  out->sig_level = 0.0;
+  *rc = 0;
+  if (r.cls == kClsAP || r.cls == kClsAP2) {
+    if (!cache.test (r.crc)) return r.cls == kClsAP ? -1 : -2;
+    out->addr = r.crc;
+    if (r.df >= 24) out->msg_type = 24;
+    return 1000;
+  }
+  const uint32_t aa = aa_after_repair (r), slot = IcaoCache::hash (aa);
+  const bool known = cache.test_at (slot, aa);
+  int score;
+  if (r.cls == kClsDF11) {
+    if ((r.crc & 0x7F) == 0) score = (known ? 1600 : 750) / (r.nerr + 1);
+    else if (!known) return -1;
+    else score = 1000 / (r.nerr + 1);
+    if (r.crc & 0xFFFF80u) {
+      out->error_bits = uint8_t (r.nerr);
+      if (r.nerr >= 1) flip (msg, r.bit0);
+      const uint32_t a2 = aa_field (msg);
+      if (!(a2 == aa ? known : cache.test (a2))) { *rc = -1; return score; }
+    }
+    out->addr = aa_field (msg);
+    if (out->error_bits == 0 && (r.crc & 0x7F) == 0) { if (out->addr == aa) cache.add_at (slot, aa); else cache.add (out->addr); }
+    return score;
+  }
+  score = (known ? 1800 : 1400) / (r.nerr + 1);
+  if (r.crc != 0) {
+    const uint32_t before = aa_field (msg);
+    out->error_bits = uint8_t (r.nerr);
+    if (r.nerr >= 1) flip (msg, r.bit0);
+    if (r.nerr >= 2) flip (msg, r.bit1);
+    const uint32_t after = aa_field (msg);
+    if ((r.nerr == 2 || (r.nerr == 1 && before != after)) && !(after == aa ? known : cache.test (after))) { *rc = -1; return score; }
+  }
+  out->addr = aa_field (msg) | non_icao_flag (msg, r.df);
+  if (out->error_bits == 0) { if (out->addr == aa) cache.add_at (slot, aa); else cache.add (out->addr); }
+  return score;
+}
+
 
 // The per-block ordered walk of demod_2400 (ref: src/demod-2400.c:200-520) over records sorted by
 // stream position.  `pos[i]` is the scan position of records[i] inside the shard.
@@ -201,10 +255,12 @@ void accept_pass_8000 (const D8Window *win, size_t nwin, const Record *rec, uint
 // wraps the bound host callbacks of the drop-in entry point).
 // `slot ()` says where the next message is to be built; `emit` is handed that place back (a caller that collects the
 // messages in an array moves on by one there, or leaves the place to the next message).
+// `own_rules`: the cache, when score and decode are this library's own score_record () / accept_record () on it: a window
+// with a single candidate then goes through score_and_accept ().
 template <class Score, class Decode, class Emit, class Slot>
 inline void accept_pass_8000_with (const D8Window *win, size_t nwin, const Record *rec, uint32_t B, int bshift, uint64_t T, uint32_t ov,
                                    uint64_t first_sample, uint32_t sample_rate, Score &&score, Decode &&decode, Emit &&emit, Slot &&slot,
-                                   Pass8000Stats &st_out)
+                                   Pass8000Stats &st_out, IcaoCache *own_rules = nullptr)
 {
   Pass8000Stats st = st_out;                                        // counted in registers, handed back at the end
   uint64_t ts_blk = ~0ull, block_ts = 0;                           // block_ts of the block seen last (it changes every 64 K samples)
@@ -212,10 +268,17 @@ inline void accept_pass_8000_with (const D8Window *win, size_t nwin, const Recor
     const D8Window &w = win[wi];
     const Record *r0 = rec + w.pad;
     int best = -1; uint32_t besti = 0;
-    for (uint32_t k = 0; k < w.nrec; k++) {                        // ref: :368-379, `if (message_result > best_result)`
-      const int sc = score (r0[k], (r0[k].phase >> 4) ? kLongBits : kShortBits);
-      if (sc > best) { best = sc; besti = k; }
-    }
+    int rc_single = 0;
+    const bool single = own_rules && w.nrec == 1;
+    if (single) {
+      modes_message *mm1 = slot ();
+      memset (mm1, 0, sizeof *mm1);
+      best = score_and_accept (r0[0], *own_rules, mm1, &rc_single);
+    } else
+      for (uint32_t k = 0; k < w.nrec; k++) {                      // ref: :368-379, `if (message_result > best_result)`
+        const int sc = score (r0[k], (r0[k].phase >> 4) ? kLongBits : kShortBits);
+        if (sc > best) { best = sc; besti = k; }
+      }
     if (best < 0) continue;
     st.valid_preamble++; st.demodulated++;                         // ref: :412, 424
     const Record &r = r0[besti];
@@ -232,8 +295,11 @@ inline void accept_pass_8000_with (const D8Window *win, size_t nwin, const Recor
     }
     const uint64_t ts = block_ts + uint64_t (int64_t ((position - kD8LookAhead - slen - int (ov)) * 12 / 8));   // ref: :421-422
     modes_message &mm = *slot ();
-    memset (&mm, 0, sizeof mm);
-    const int rc = decode (r, ts, &mm);
+    int rc = rc_single;
+    if (!single) {
+      memset (&mm, 0, sizeof mm);
+      rc = decode (r, ts, &mm);
+    }
     if (rc < 0) { st.CRC_bad++; if (rc == -1) st.rejected_unknown++; continue; }
     if (mm.error_bits == 1) st.CRC_single_bit_fix++; else if (mm.error_bits == 2) st.CRC_two_bits_fix++; else st.CRC_good++;
     mm.timestamp = ts;

@@ -1599,7 +1599,7 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
           }
           nm++;                                                     // the message stays where it was built
         },
-        [&] { return mout + nm; }, ps);
+        [&] { return mout + nm; }, ps, &cache);
       e->messages.resize (m0 + nm);
       host_ms += std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - t_host0).count ();
       if (timing) fprintf (stderr, ", walked %llu windows / %llu records in %.3f ms", (unsigned long long) nwin, (unsigned long long) nrec,
