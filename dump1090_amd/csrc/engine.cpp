@@ -1459,13 +1459,15 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
     HIP_TRY (hipEventRecord (e->d8_events[3 * r], stream));
     if (!same_windows) HIP_TRY (launch_d8_windows (q, n, stream, 1));
     HIP_TRY (hipEventRecord (e->d8_events[3 * r + 1], stream));
-    if (r == 1 && !same_windows) HIP_TRY (hipStreamWaitEvent (stream, e->d8_edges_done, 0));
-    HIP_TRY (launch_d8_count (q, n, e->d8_chunk_rec.p, stream));
+    // Count, offsets and gather of the range run on the second stream beside the next range's window kernel, which
+    // leaves the caller's stream to the window kernels alone.  The address filter of count (r) may then also see what
+    // windows of range r + 1 have announced by the time it runs: a record more is kept now and then (its address is not
+    // in the cache when the walk gets there, so it changes nothing but `candidates`).
+    HIP_TRY (hipStreamWaitEvent (side, e->d8_events[3 * r + 1], 0));
+    if (r == 1 && !same_windows) HIP_TRY (hipStreamWaitEvent (side, e->d8_edges_done, 0));
+    HIP_TRY (launch_d8_count (q, n, e->d8_chunk_rec.p, side));
     HIP_TRY (launch_d8_offsets (e->d8_chunk_rec.p, e->d8_win_count.p, nchunks, c0, n, e->d8_off.p, e->d8_off.p + nchunks + 1,
-                                uint64_t (n) * bw, uint64_t (n) * br, e->d8_tot.p + 4 * r, e->pin_tot.p + 4 * r, stream));
-    // the gather only reads what count and offsets left: it runs beside the next range's window kernel
-    HIP_TRY (hipEventRecord (e->d8_events[3 * r + 2], stream));
-    HIP_TRY (hipStreamWaitEvent (side, e->d8_events[3 * r + 2], 0));
+                                uint64_t (n) * bw, uint64_t (n) * br, e->d8_tot.p + 4 * r, e->pin_tot.p + 4 * r, side));
     HIP_TRY (launch_d8_gather (q, n, e->d8_off.p, e->d8_off.p + nchunks + 1, e->pin_wins.p + size_t (c0) * bw, e->pin_recs.p + size_t (c0) * br,
                                side, e->d8_tot.p + 4 * r));
     HIP_TRY (hipEventRecord (e->d8_gathered[r], side));
