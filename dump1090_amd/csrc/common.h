@@ -57,7 +57,10 @@ constexpr int kD8LookAhead = 544, kD8LookBack = 1384, kD8Overlap = 1928, kD8Win 
 constexpr int kD8Ambig = 4576;           // 2*max > 3*av is settled without av above this: av <= 50000000 >> 14 = 3051
 constexpr int kD8SaneMax = 50000000;
 constexpr int kD8StripSteps = 256;       // bit steps (8 samples each) per wave of the trigger kernel
-constexpr int kD8ChunkSteps = 65536;     // bit steps per chunk of the window-chain kernels
+#ifndef D8_CHUNK_STEPS
+#define D8_CHUNK_STEPS 65536
+#endif
+constexpr int kD8ChunkSteps = D8_CHUNK_STEPS;     // bit steps per chunk of the window-chain kernels
 constexpr int kD8WinCap = kD8ChunkSteps / kD8Net + 6;   // openings are >= kD8Net steps apart (580 in a chunk); the first chunk also lists up to three carried in from the steps before it
 constexpr int kD8Cand = 32;              // candidate messages per window: 16 bit shifts x (short, long)
 

@@ -23,6 +23,9 @@
 #ifndef D8WIN_WAVES
 #define D8WIN_WAVES 7     // 71 registers, nothing spilled; 7 x 22 KB of LDS per CU
 #endif
+#ifndef D8_WIN_GRIDY
+#define D8_WIN_GRIDY 16     // workgroups per chunk of the window kernel
+#endif
 #ifndef D8TRIG_WAVES
 #define D8TRIG_WAVES 6
 #endif
@@ -881,7 +884,7 @@ hipError_t launch_d8_chain (const D8Params &q, unsigned long long trig_tail, lon
 hipError_t launch_d8_windows (const D8Params &q, uint32_t nch, hipStream_t stream, int which)
 {
   if (nch == 0) return hipSuccess;
-  const dim3 grid (nch, 16), block (64 * kW8);
+  const dim3 grid (nch, D8_WIN_GRIDY), block (64 * kW8);
   if (which & 1) { D8_DISPATCH (d8_window_kernel, grid, block, q); }
   // a few windows per block edge: fewer, longer-lived waves (each looks at 64 windows per pass)
   const dim3 edge_grid (nch, 4);
