@@ -271,6 +271,18 @@ __device__ __forceinline__ long long first_trig (const u64 *bm, int nwords, long
   return (long long) wi * 64 + __builtin_ctzll (word);
 }
 
+// the same inside one chunk, where every position fits an int (the hops of the chain kernels are dependent: fewer
+// operations per hop is what makes them shorter)
+__device__ __forceinline__ int first_trig32 (const u64 *bm, int nwords, int rel)
+{
+  int wi = rel >> 6;
+  if (wi >= nwords) return -1;
+  u64 word = bm[wi] >> (rel & 63);
+  if (word) return rel + __builtin_ctzll (word);
+  while (++wi < nwords) { word = bm[wi]; if (word) return wi * 64 + __builtin_ctzll (word); }
+  return -1;
+}
+
 // table[chunk][r] = where the search stands, relative to the end of the chunk, when it entered at offset r
 __global__ __launch_bounds__ (128)
 void d8_chain_table_kernel (const D8Params q)
@@ -283,11 +295,12 @@ void d8_chain_table_kernel (const D8Params q)
   __syncthreads ();
   const int r = threadIdx.x;
   if (r >= kD8Net) return;
-  long long pos = r, len = n_hi - n_lo;
+  int pos = r;
+  const int len = int (n_hi - n_lo);
   int exit_off = 0;
   for (;;) {
-    if (pos >= len) { exit_off = int (min (pos - len, (long long) (kD8Net - 1))); break; }
-    const long long s = first_trig (bm, nwords, pos);
+    if (pos >= len) { exit_off = min (pos - len, kD8Net - 1); break; }
+    const int s = first_trig32 (bm, nwords, pos);
     if (s < 0) { exit_off = 0; break; }
     pos = s + kD8Net;
   }
@@ -385,11 +398,15 @@ void d8_chain_walk_kernel (const D8Params q, const long long *pre, long long *pe
       const long long s = pre[1 + k];
       if (s + kD8Win <= (long long) q.nsteps) ws[n++] = s; else *pending_out = s - (long long) q.nsteps;
     }
-  long long pos = q.entry[c], len = n_hi - n_lo;
+  int pos = q.entry[c];
+  const int len = int (n_hi - n_lo);
+  // openings at or behind `last_whole` are cut off by the end of the stream
+  const long long room = (long long) q.nsteps - kD8Win - n_lo;            // s <= room: the window is whole
+  const int last_whole = room >= len ? len : room < 0 ? -1 : int (room);
   while (pos < len) {
-    const long long s = first_trig (bm, nwords, pos);
+    const int s = first_trig32 (bm, nwords, pos);
     if (s < 0) break;
-    if (n_lo + s + kD8Win <= (long long) q.nsteps) { if (n < uint32_t (kD8WinCap)) ws[n] = n_lo + s; n++; }
+    if (s <= last_whole) { if (n < uint32_t (kD8WinCap)) ws[n] = n_lo + s; n++; }
     else { *pending_out = n_lo + s - (long long) q.nsteps; break; }   // the stream ends inside this window: nothing opens after it
     pos = s + kD8Net;
   }
