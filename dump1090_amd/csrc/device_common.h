@@ -378,6 +378,53 @@ __device__ __forceinline__ void stage_tile_pos (uint16_t *tile, const uint16_t *
   }
 }
 
+// The same with a run-time length (count <= kMaxCount): the windows a workgroup of d8_window_kernel works on at a time
+// lie as far apart as the triggers were.
+template <int CONV, int kMaxCount, int kLanes>
+__device__ __forceinline__ void stage_span_pos (uint16_t *tile, const uint16_t *lut, const ScanParams &p, long long s0, int count, int lane)
+{
+  constexpr int kIters = (TileChunks<kMaxCount>::n + kLanes - 1) / kLanes;
+  constexpr int NW = RawWords<CONV>::n;
+  const int nchunks = (count + 14) / 8;
+  const long long N = (long long) (CONV == kConvMagU16 ? p.navail : p.nsamples);
+  const long long a_lo = (s0 >= 0 ? s0 : s0 - 7) / 8 * 8;
+  const int shift = int (s0 - a_lo);
+  if (a_lo >= 0 && a_lo + 8 * nchunks <= N) {
+    uint32_t raw[kIters][NW];
+#pragma unroll
+    for (int it = 0; it < kIters; it++) {
+      const int ch = it * kLanes + lane;
+      if (ch < nchunks) load_raw8<CONV> (p, a_lo + 8 * ch, raw[it]);
+    }
+#pragma unroll
+    for (int it = 0; it < kIters; it++) {
+      const int ch = it * kLanes + lane;
+      if (ch < nchunks) {
+        const uint4 pk = convert_raw8<CONV> (lut, raw[it]);
+        uint16_t *dst = tile + 8 * ch - shift;
+        if (shift == 0) *reinterpret_cast<uint4 *> (dst) = pk;
+        else if (!(shift & 1)) {
+          uint32_t *d32 = reinterpret_cast<uint32_t *> (dst);
+          d32[0] = pk.x; d32[1] = pk.y; d32[2] = pk.z; d32[3] = pk.w;
+        } else {
+          dst[0] = uint16_t (pk.x); dst[1] = uint16_t (pk.x >> 16); dst[2] = uint16_t (pk.y); dst[3] = uint16_t (pk.y >> 16);
+          dst[4] = uint16_t (pk.z); dst[5] = uint16_t (pk.z >> 16); dst[6] = uint16_t (pk.w); dst[7] = uint16_t (pk.w >> 16);
+        }
+      }
+    }
+    return;
+  }
+  for (int c = lane * 8; c < (count + 7) / 8 * 8; c += kLanes * 8) {
+    uint16_t out[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) out[k] = mag_of_sample<CONV> (lut, p, s0 + c + k, N);
+    uint4 pk;
+    pk.x = out[0] | (uint32_t (out[1]) << 16); pk.y = out[2] | (uint32_t (out[3]) << 16);
+    pk.z = out[4] | (uint32_t (out[5]) << 16); pk.w = out[6] | (uint32_t (out[7]) << 16);
+    *reinterpret_cast<uint4 *> (&tile[c]) = pk;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // kConvUc8LutR8: the tile holds one byte per sample, the rank of its magnitude among the byte table's values
 // (comparisons of ranks are comparisons of magnitudes; rankmag[rank] gives the magnitude back).

@@ -14,6 +14,7 @@
 //   * each completed window is independent work                                  -> d8_window_kernel
 // What needs the ICAO cache (which candidate wins, accept) is left to the ordered pass over the windows' records.
 // "ref:" citations are relative to the reference's root.
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "common.h"
@@ -75,6 +76,23 @@ struct WinLds {
   uint16_t lut[256];
 };
 
+// d8_window_kernel: the four waves of a workgroup work on four neighbouring windows of the chunk at a time.  Openings
+// are at least kD8Net steps apart and mostly not much more, so neighbouring windows overlap by half: where the four fit
+// (nearly always) they share ONE position-aligned tile staged by all 256 threads, else every wave stages its own
+// quarter of it.
+constexpr int kWinNeed = 1944;                                   // samples a window reads: 8 * 241 + 8 differences, each m[j] - m[j+4]
+constexpr int kWinQuarter = 1960;                                // 8 * TileChunks<kWinNeed>::n plus the slack in front of the next one
+constexpr int kWinGroupTile = kW8 * kWinQuarter;
+struct WinPerWave {
+  int32_t  match[kD8Win];
+  uint8_t  par[kD8Win + 8];
+};
+struct WinGroupLds {
+  __attribute__ ((aligned (16))) uint16_t tile[kTileLead + 8 * TileChunks<kWinGroupTile>::n];
+  WinPerWave per[kW8];
+  uint16_t lut[256];
+};
+
 // The windows at a block edge (d8_window_edge_kernel): their differences come from three places (this call's magnitudes,
 // the differences carried in, what the previous call left in the buffer), so they are formed once, by all lanes side by
 // side, and the window reads them here.
@@ -83,10 +101,11 @@ struct WinEdgeLds {
   WinLds  base;
   int32_t diff[kWinDiffs];
 };
-__device__ __forceinline__ WinLds &base_of (WinLds &w) { return w; }
-__device__ __forceinline__ WinLds &base_of (WinEdgeLds &w) { return w.base; }
-__device__ __forceinline__ int32_t *diffs_of (WinLds &) { return nullptr; }
-__device__ __forceinline__ int32_t *diffs_of (WinEdgeLds &w) { return w.diff; }
+// what a wave of either kernel works with
+struct WinView { uint16_t *tile; int32_t *match; uint8_t *par; uint16_t *lut; int32_t *diff; };
+__device__ __forceinline__ WinView view_of (WinGroupLds *l, int wv) { return { l->tile + kTileLead, l->per[wv].match, l->per[wv].par, l->lut, nullptr }; }
+__device__ __forceinline__ WinView view_of (WinLds *l, int wv) { return { l[wv].tile, l[wv].match, l[wv].par, l[wv].lut, nullptr }; }
+__device__ __forceinline__ WinView view_of (WinEdgeLds *l, int wv) { return { l[wv].base.tile, l[wv].base.match, l[wv].base.par, l[wv].base.lut, l[wv].diff }; }
 
 // |a - b| + c in one VALU operation (v_sad_u32); the compiler does not form it from the C expression
 __device__ __forceinline__ uint32_t sad_u32 (uint32_t a, uint32_t b, uint32_t c)
@@ -424,15 +443,17 @@ void d8_chain_walk_kernel (const D8Params q, const long long *pre, long long *pe
 template <int CONV, bool PLAIN, typename Lds>
 __device__ __forceinline__ void d8_window_body (const D8Params &q, Lds *lds, uint32_t *crc_tab)
 {
+  constexpr bool GROUP = std::is_same<Lds, WinGroupLds>::value;              // the workgroup's four windows at a time share a tile
   const int lane0 = lane_id ();
   const int wv = __builtin_amdgcn_readfirstlane (int (threadIdx.x >> 6));    // wave-uniform: what derives from it is scalar arithmetic
-  WinLds &w = base_of (lds[wv]);
-  int32_t *const diff = diffs_of (lds[wv]);
+  const WinView w = view_of (lds, wv);
+  int32_t *const diff = w.diff;
   crc_tab[threadIdx.x & 255] = q.sp.crc_table[threadIdx.x & 255];
-  __syncthreads ();
   const uint32_t chunk = q.chunk0 + blockIdx.x;
   const uint32_t nwin = min (q.win_count[chunk], uint32_t (kD8WinCap));
-  for (int i = lane0; i < 256; i += 64) w.lut[i] = q.sp.lut256 ? q.sp.lut256[i] : uint16_t (0);
+  if (GROUP) for (int i = int (threadIdx.x); i < 256; i += 64 * kW8) w.lut[i] = q.sp.lut256 ? q.sp.lut256[i] : uint16_t (0);
+  else for (int i = lane0; i < 256; i += 64) w.lut[i] = q.sp.lut256 ? q.sp.lut256[i] : uint16_t (0);
+  __syncthreads ();
 
   // The block whose demod_8000 call completes the window that opens at step s, and how far that call's buffer is filled
   // (ref: :203-215); `plain`: every difference of the window is m[j] - m[j+4] inside one block of the stream (no block
@@ -449,16 +470,23 @@ __device__ __forceinline__ void d8_window_body (const D8Params &q, Lds *lds, uin
 
   // The windows of a chunk go round the waves of its workgroups.  Lane j looks at the j-th window of this wave: which of
   // them are this kernel's is settled for all of them at once, and each one's opening step is then a scalar.
+  // With a shared tile the workgroup goes through the groups of four in step (every wave of the workgroup takes part in the staging
+  // of a group, whether its own window of it is this kernel's or not); otherwise the waves each go their own way.
   const uint32_t stride = gridDim.y * kW8;
-  for (uint32_t kb = blockIdx.y * kW8 + wv; kb < nwin; kb += 64 * stride) {
+  const int64_t *const starts = q.win_start + size_t (chunk) * kD8WinCap;
+  for (uint32_t kb0 = blockIdx.y * kW8; kb0 < nwin; kb0 += 64 * stride) {
+  const uint32_t kb = kb0 + uint32_t (wv);
   const uint32_t kl = kb + uint32_t (lane0) * stride;
   long long s_lane = 0;
   bool mine = false;
-  if (kl < nwin) { s_lane = q.win_start[size_t (chunk) * kD8WinCap + kl]; mine = plain_of (s_lane) == PLAIN; }
+  if (kl < nwin) { s_lane = starts[kl]; mine = plain_of (s_lane) == PLAIN; }
   u64 todo = __ballot (mine);
-  while (todo) {
-    const int pick = __builtin_ctzll (todo);
-    todo &= todo - 1;
+  const int npick = int (min (64u, (nwin - kb0 + stride - 1) / stride));
+  int pick = -1;
+  while (true) {
+    bool my = true;
+    if constexpr (GROUP) { if (++pick >= npick) break; my = (todo >> pick) & 1; }
+    else { if (!todo) break; pick = __builtin_ctzll (todo); todo &= todo - 1; }
     const uint32_t k = kb + uint32_t (pick) * stride;
     const long long s = (long long) (u64 (uint32_t (__builtin_amdgcn_readlane (int (uint32_t (u64 (s_lane))), pick)))
                                      | u64 (uint32_t (__builtin_amdgcn_readlane (int (uint32_t (u64 (s_lane) >> 32)), pick))) << 32);
@@ -475,12 +503,38 @@ __device__ __forceinline__ void d8_window_body (const D8Params &q, Lds *lds, uin
     const long long fill_g = fill_of (blkc);
     const long long Plo = gbase - kD8LookAhead;
 
-    __builtin_amdgcn_s_waitcnt (0xc07f);
-    __builtin_amdgcn_wave_barrier ();
-    stage_tile<CONV, kWinTile> (w.tile, w.lut, q.sp, a_lo, lane);
-    __builtin_amdgcn_s_waitcnt (0xc07f);
-    __builtin_amdgcn_wave_barrier ();
-    const int tbase = int (Plo - x0);                                        // tile index of the sample behind D'[gbase]
+    int tbase;                                                               // tile index of the sample behind D'[gbase]
+    if constexpr (GROUP) {
+      // the group's span: from the first of its windows' opening steps to the last (listed in order but for what a
+      // chunk takes over from the one before, so the four are looked at)
+      const uint32_t kf = kb0 + uint32_t (pick) * stride;
+      long long s_min = starts[kf], s_max = s_min;
+#pragma unroll
+      for (uint32_t j = 1; j < uint32_t (kW8); j++) {
+        const long long sj = starts[min (kf + j, nwin - 1)];
+        s_min = min (s_min, sj); s_max = max (s_max, sj);
+      }
+      const long long ov = (long long) (CONV == kConvMagU16 ? 0u : q.sp.ov);
+      const long long xlo_min = 8 * (s_min - 4) - kD8LookAhead;
+      const long long span = 8 * (s_max - s_min) + kWinNeed;
+      const bool shared = span <= kWinGroupTile;
+      tbase = shared ? int (xlo - xlo_min) : wv * kWinQuarter;
+      __syncthreads ();                                                      // every wave is through with the tile of the group before
+#pragma unroll 1
+      for (int r = 0; r < (shared ? 1 : kW8); r++) {                         // all 256 threads stage: the span, or one window after the other
+        const long long x_r = shared ? xlo_min : 8 * ((long long) starts[min (kf + uint32_t (r), nwin - 1)] - 4) - kD8LookAhead;
+        stage_span_pos<CONV, kWinGroupTile, 64 * kW8> (w.tile + r * kWinQuarter, w.lut, q.sp, x_r - ov, shared ? int (span) : kWinNeed, int (threadIdx.x));
+      }
+      __syncthreads ();
+      if (!my) continue;
+    } else {
+      __builtin_amdgcn_s_waitcnt (0xc07f);
+      __builtin_amdgcn_wave_barrier ();
+      stage_tile<CONV, kWinTile> (w.tile, w.lut, q.sp, a_lo, lane);
+      __builtin_amdgcn_s_waitcnt (0xc07f);
+      __builtin_amdgcn_wave_barrier ();
+      tbase = int (Plo - x0);
+    }
     auto dval_edge = [&] (int idx) -> int {
       const long long g = gbase + idx;
       if (g < fill_g) return dprime_tile (q, w.tile, x0, g);
@@ -649,7 +703,10 @@ template <int CONV>
 __global__ __launch_bounds__ (64 * kW8) __attribute__ ((amdgpu_waves_per_eu (D8WIN_WAVES, D8WIN_WAVES)))
 void d8_window_kernel (const D8Params q)
 {
-  __shared__ WinLds lds[kW8];
+  // the float converters hold too many registers through a staging pass of four rounds of 256 threads, and the magnitudes
+  // of the drop-in boundary have nothing to convert: those keep a tile per wave
+  constexpr bool kGroup = CONV != kConvSc16Generic && CONV != kConvSc16Q11Generic && CONV != kConvMagU16;
+  __shared__ std::conditional_t<kGroup, WinGroupLds, WinLds> lds[kGroup ? 1 : kW8];
   __shared__ uint32_t crc_tab[256];
   d8_window_body<CONV, true> (q, lds, crc_tab);
 }

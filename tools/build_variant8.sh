@@ -4,4 +4,4 @@ tag=$1; shift
 cd "$(dirname "$0")/../dump1090_amd/csrc" || exit 1
 make -s || exit 1
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-result --offload-arch=gfx950 -ffp-contract=off "$@" -c kernels_8000.hip -o /tmp/kernels8_$tag.o || exit 1
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../libmodes_hip_$tag.so kernels.o kernels_2000.o kernels_ac.o /tmp/kernels8_$tag.o kernels_dc.o engine.o dropin.o accept.o tables.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../libmodes_hip_$tag.so kernels.o kernels_2000.o kernels_ac.o /tmp/kernels8_$tag.o kernels_dc.o noalloc.o strip.o kernels_fields.o engine.o live.o dropin.o accept.o tables.o
