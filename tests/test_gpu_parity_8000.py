@@ -72,6 +72,23 @@ def test_messages_straddling_block_boundaries():
     check(iq, "sc16", len(offs) - 3)
 
 
+def test_windows_far_apart_take_a_tile_each():
+    """Bursts in silence: the four windows a workgroup of d8_window_kernel takes at a time lie further apart than its
+    shared tile is long, so every wave stages its own quarter (the other tests' windows tile the stream)."""
+    rng = np.random.default_rng(91)
+    nb = 120
+    x = np.zeros(4000 + 9000 * nb, dtype=np.complex128)
+    for b in range(nb):
+        p = 4000 + 9000 * b + int(rng.integers(0, 64))
+        x[p - 600:p + 1700] = (rng.standard_normal(2300) + 1j * rng.standard_normal(2300)) * 0.004
+        msg = synth.make_df17(0x3C6000 + b, bytes(rng.integers(0, 256, 7, dtype=np.uint8)))
+        env = synth.envelope(msg, 8.0e6, rng.random())
+        x[p:p + len(env)] += 0.25 * np.exp(2j * np.pi * rng.random()) * env
+    iq = synth.quantise(x, "sc16")
+    check(iq, "sc16", nb // 2)
+    check(synth.quantise(x, "uc8"), "uc8", 0)
+
+
 def test_long_recording_runs_in_chunk_ranges():
     """Sixteen chunks and more (8.4 M samples) make the engine walk the windows in four ranges, each range's ordered
     pass on the host overlapping the next range's kernels: the message list must not notice the seams."""
