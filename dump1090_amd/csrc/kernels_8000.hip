@@ -14,6 +14,7 @@
 //   * each completed window is independent work                                  -> d8_window_kernel
 // What needs the ICAO cache (which candidate wins, accept) is left to the ordered pass over the windows' records.
 // "ref:" citations are relative to the reference's root.
+#include <limits.h>
 #include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -296,36 +297,67 @@ __device__ __forceinline__ long long first_trig (const u64 *bm, int nwords, long
 // operations per hop is what makes them shorter)
 __device__ __forceinline__ int first_trig32 (const u64 *bm, int nwords, int rel)
 {
-  int wi = rel >> 6;
-  if (wi >= nwords) return -1;
-  u64 word = bm[wi] >> (rel & 63);
-  if (word) return rel + __builtin_ctzll (word);
-  while (++wi < nwords) { word = bm[wi]; if (word) return wi * 64 + __builtin_ctzll (word); }
+  const uint32_t *bm32 = reinterpret_cast<const uint32_t *> (bm);           // the bitmap in 32-bit words: one shift, one v_ffbl per hop
+  const int n32 = 2 * nwords;
+  int wi = rel >> 5;
+  if (wi >= n32) return -1;
+  uint32_t word = bm32[wi] >> (rel & 31);
+  if (word) return rel + __builtin_ctz (word);
+  while (++wi < n32) { word = bm32[wi]; if (word) return wi * 32 + __builtin_ctz (word); }
   return -1;
 }
 
+// A hop of the chain is a dependent LDS read and a dozen dependent operations (260 ns), and a chunk is 580 of them: the
+// chunk is cut into kD8Subs parts whose tables (exit offset and number of openings for every entry offset) are formed
+// side by side, kD8Subs x 113 threads of 36 hops, and composed afterwards -- kD8Subs dependent look-ups.
+constexpr int kD8Subs = 16, kD8SubSteps = kD8ChunkSteps / kD8Subs, kD8ChainThreads = 1024, kD8WalkThreads = 256;
+constexpr int kD8SubBytes = 2 * kD8Subs * 128;                  // per chunk: exits and counts of its parts, what D8Params::table holds behind [nchunks][128]
+static_assert (kD8SubBytes == D8_TABLE_BYTES_PER_CHUNK - 128, "the hosts size D8Params::table by D8_TABLE_BYTES_PER_CHUNK");
+static_assert (kD8SubSteps % 64 == 0 && kD8SubSteps / kD8Net < 255, "a part is whole bitmap words; its count fits a byte");
+
+template <bool COUNT>
+__device__ __forceinline__ void d8_sub_tables (const u64 *bm, int len, uint8_t (*sub_tab)[128], uint8_t (*sub_cnt)[128])
+{
+  for (int item = threadIdx.x; item < kD8Subs * 128; item += kD8ChainThreads) {
+    const int j = item >> 7, r = item & 127;
+    if (r >= kD8Net) continue;
+    const int sublen = max (0, min (kD8SubSteps, len - j * kD8SubSteps));
+    const int nw = (sublen + 63) >> 6;
+    int pos = r, exit_off = 0, cnt = 0;
+    for (;;) {
+      if (pos >= sublen) { exit_off = min (pos - sublen, kD8Net - 1); break; }
+      const int s = first_trig32 (bm + j * (kD8SubSteps / 64), nw, pos);
+      if (s < 0) { exit_off = 0; break; }                      // nothing more in this part: the search goes on at the start of the next
+      cnt++;
+      pos = s + kD8Net;
+    }
+    sub_tab[j][r] = uint8_t (exit_off);
+    if (COUNT) sub_cnt[j][r] = uint8_t (cnt);
+  }
+}
+
 // table[chunk][r] = where the search stands, relative to the end of the chunk, when it entered at offset r
-__global__ __launch_bounds__ (128)
+__global__ __launch_bounds__ (kD8ChainThreads)
 void d8_chain_table_kernel (const D8Params q)
 {
   __shared__ u64 bm[kD8ChunkSteps / 64];
+  __shared__ __attribute__ ((aligned (16))) uint8_t sub_tab[2 * kD8Subs][128];         // exits, then counts
   const uint32_t c = blockIdx.x;
   const long long n_lo = (long long) c * kD8ChunkSteps, n_hi = min (n_lo + (long long) kD8ChunkSteps, (long long) q.nsteps);
   const int nwords = int ((n_hi - n_lo + 63) >> 6);
-  for (int i = threadIdx.x; i < nwords; i += 128) bm[i] = q.trig[(n_lo >> 6) + i];
+  for (int i = threadIdx.x; i < kD8ChunkSteps / 64; i += kD8ChainThreads) bm[i] = i < nwords ? q.trig[(n_lo >> 6) + i] : 0;
   __syncthreads ();
+  d8_sub_tables<true> (bm, int (n_hi - n_lo), sub_tab, sub_tab + kD8Subs);
+  __syncthreads ();
+  // the walk kernel reads them back (they lie behind the chunks' own tables)
+  if (threadIdx.x < kD8SubBytes / 16)
+    reinterpret_cast<uint4 *> (q.table + size_t (q.nchunks) * 128 + size_t (c) * kD8SubBytes)[threadIdx.x] = reinterpret_cast<const uint4 *> (&sub_tab[0][0])[threadIdx.x];
   const int r = threadIdx.x;
   if (r >= kD8Net) return;
-  int pos = r;
-  const int len = int (n_hi - n_lo);
-  int exit_off = 0;
-  for (;;) {
-    if (pos >= len) { exit_off = min (pos - len, kD8Net - 1); break; }
-    const int s = first_trig32 (bm, nwords, pos);
-    if (s < 0) { exit_off = 0; break; }
-    pos = s + kD8Net;
-  }
-  q.table[size_t (c) * 128 + r] = uint8_t (exit_off);
+  uint32_t e = uint32_t (r);
+#pragma unroll
+  for (int j = 0; j < kD8Subs; j++) e = sub_tab[j][e];
+  q.table[size_t (c) * 128 + r] = uint8_t (e);
 }
 
 // One thread: what happens before step 0 (a window carried in, triggers among the last steps of the previous
@@ -402,36 +434,62 @@ void d8_chain_exit_kernel (const D8Params q, int32_t *exit_of)
 }
 
 // per chunk: the window openings themselves; the last one may still be open when the stream ends
-__global__ __launch_bounds__ (64)
+// The parts' tables of the table kernel give the entry offset and the place in the list of every part by composition,
+// then one lane per part writes its openings.
+__global__ __launch_bounds__ (kD8WalkThreads)
 void d8_chain_walk_kernel (const D8Params q, const long long *pre, long long *pending_out)
 {
   __shared__ u64 bm[kD8ChunkSteps / 64];
+  __shared__ __attribute__ ((aligned (16))) uint8_t sub_tab[2 * kD8Subs][128];
+  uint8_t (*const sub_cnt)[128] = sub_tab + kD8Subs;
+  __shared__ int s_entry[kD8Subs], s_off[kD8Subs], s_whole[kD8Subs], s_cut[kD8Subs];
   const uint32_t c = blockIdx.x;
   const long long n_lo = (long long) c * kD8ChunkSteps, n_hi = min (n_lo + (long long) kD8ChunkSteps, (long long) q.nsteps);
   const int nwords = int ((n_hi - n_lo + 63) >> 6);
-  for (int i = threadIdx.x; i < nwords; i += 64) bm[i] = q.trig[(n_lo >> 6) + i];
-  __syncthreads ();
-  if (threadIdx.x) return;
-  int64_t *ws = q.win_start + size_t (c) * kD8WinCap;
-  uint32_t n = 0;
-  if (c == 0)
-    for (int k = 0; k < int (pre[0]); k++) {
-      const long long s = pre[1 + k];
-      if (s + kD8Win <= (long long) q.nsteps) ws[n++] = s; else *pending_out = s - (long long) q.nsteps;
-    }
-  int pos = q.entry[c];
   const int len = int (n_hi - n_lo);
+  for (int i = threadIdx.x; i < kD8ChunkSteps / 64; i += kD8WalkThreads) bm[i] = i < nwords ? q.trig[(n_lo >> 6) + i] : 0;
+  for (int i = threadIdx.x; i < kD8SubBytes / 16; i += kD8WalkThreads)
+    reinterpret_cast<uint4 *> (&sub_tab[0][0])[i] = reinterpret_cast<const uint4 *> (q.table + size_t (q.nchunks) * 128 + size_t (c) * kD8SubBytes)[i];
+  __syncthreads ();
+  int64_t *ws = q.win_start + size_t (c) * kD8WinCap;
+  if (threadIdx.x == 0) {
+    int n = 0;
+    if (c == 0)
+      for (int k = 0; k < int (pre[0]); k++) {
+        const long long s = pre[1 + k];
+        if (s + kD8Win <= (long long) q.nsteps) ws[n++] = s; else atomicMin (pending_out, s - (long long) q.nsteps);
+      }
+    uint32_t e = q.entry[c];
+    for (int j = 0; j < kD8Subs; j++) { s_entry[j] = int (e); s_off[j] = n; n += sub_cnt[j][e]; e = sub_tab[j][e]; }
+  }
+  __syncthreads ();
   // openings at or behind `last_whole` are cut off by the end of the stream
   const long long room = (long long) q.nsteps - kD8Win - n_lo;            // s <= room: the window is whole
   const int last_whole = room >= len ? len : room < 0 ? -1 : int (room);
-  while (pos < len) {
-    const int s = first_trig32 (bm, nwords, pos);
-    if (s < 0) break;
-    if (s <= last_whole) { if (n < uint32_t (kD8WinCap)) ws[n] = n_lo + s; n++; }
-    else { *pending_out = n_lo + s - (long long) q.nsteps; break; }   // the stream ends inside this window: nothing opens after it
-    pos = s + kD8Net;
+  if (threadIdx.x < kD8Subs) {
+    const int j = threadIdx.x;
+    const int sublen = max (0, min (kD8SubSteps, len - j * kD8SubSteps));
+    const int nw = (sublen + 63) >> 6;
+    int pos = s_entry[j], i = s_off[j], cut = INT_MAX;
+    while (pos < sublen) {
+      const int s = first_trig32 (bm + j * (kD8SubSteps / 64), nw, pos);
+      if (s < 0) break;
+      const int S = j * kD8SubSteps + s;                                 // relative to the chunk
+      if (S <= last_whole) { if (i < kD8WinCap) ws[i] = n_lo + S; i++; }
+      else { cut = S; break; }                                           // the stream ends inside this window: nothing opens after it
+      pos = s + kD8Net;
+    }
+    s_whole[j] = i - s_off[j];
+    s_cut[j] = cut;
   }
-  q.win_count[c] = n;
+  __syncthreads ();
+  if (threadIdx.x == 0) {
+    int n = s_off[0], cut = INT_MAX;
+    for (int j = 0; j < kD8Subs; j++) { n += s_whole[j]; cut = min (cut, s_cut[j]); }
+    // the first window the stream ends in stays open (a chunk shorter than a window may lie behind it and see triggers too)
+    if (cut != INT_MAX) atomicMin (pending_out, n_lo + cut - (long long) q.nsteps);
+    q.win_count[c] = uint32_t (n);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -937,7 +995,7 @@ hipError_t launch_d8_acc (const D8Params &q, uint64_t limit, int32_t *acc_out, h
 
 hipError_t launch_d8_chain_table (const D8Params &q, hipStream_t stream)
 {
-  if (q.nchunks) hipLaunchKernelGGL (d8_chain_table_kernel, dim3 (q.nchunks), dim3 (128), 0, stream, q);
+  if (q.nchunks) hipLaunchKernelGGL (d8_chain_table_kernel, dim3 (q.nchunks), dim3 (kD8ChainThreads), 0, stream, q);
   return hipGetLastError ();
 }
 
@@ -952,7 +1010,7 @@ hipError_t launch_d8_chain (const D8Params &q, unsigned long long trig_tail, lon
                             long long *pending_out, hipStream_t stream)
 {
   hipLaunchKernelGGL (d8_chain_resolve_kernel, dim3 (1), dim3 (256), 0, stream, q, (u64) trig_tail, search0, pre);
-  if (q.nchunks) hipLaunchKernelGGL (d8_chain_walk_kernel, dim3 (q.nchunks), dim3 (64), 0, stream, q, pre, pending_out);
+  if (q.nchunks) hipLaunchKernelGGL (d8_chain_walk_kernel, dim3 (q.nchunks), dim3 (kD8WalkThreads), 0, stream, q, pre, pending_out);
   return hipGetLastError ();
 }
 

@@ -51,7 +51,7 @@ def test_sc16_generic_power_path():
     check(iq, "sc16", 100, compute_power=True)
 
 
-@pytest.mark.parametrize("nsamples", [0, 7, 8, 543, 544, 1400, 2047, 65536, 65537, 65536 * 2 + 4321])
+@pytest.mark.parametrize("nsamples", [0, 7, 8, 543, 544, 1400, 2047, 65536, 65537, 65536 * 2 + 4321, 65536 * 8 + 700, 65536 * 16 + 1300])
 def test_ragged_lengths(nsamples):
     iq, _ = synth.capture(max(nsamples, 1), 8.0e6, "sc16", seed=84, frames_per_sec=4000, min_amp_db=-12)
     iq = iq[: 2 * nsamples]
