@@ -62,6 +62,7 @@ constexpr int kD8StripSteps = 256;       // bit steps (8 samples each) per wave 
 #endif
 constexpr int kD8ChunkSteps = D8_CHUNK_STEPS;     // bit steps per chunk of the window-chain kernels
 #define D8_TABLE_BYTES_PER_CHUNK (128 + 2 * 16 * 128)
+#define D8_TABLE_BYTES(nchunks) (size_t (nchunks) * D8_TABLE_BYTES_PER_CHUNK + (size_t (nchunks) / 64 + 1) * 128)   /* + the tables of groups of 64 chunks */
 constexpr int kD8WinCap = kD8ChunkSteps / kD8Net + 6;   // openings are >= kD8Net steps apart (580 in a chunk); the first chunk also lists up to three carried in from the steps before it
 constexpr int kD8Cand = 32;              // candidate messages per window: 16 bit shifts x (short, long)
 
@@ -185,7 +186,8 @@ struct D8Params {
   int32_t         acc0;          // d8m_phase_av_acc at the start of the stream
   int64_t         pending;       // step (< 0) at which a window carried in from a previous call opened, or 1 = none
   uint8_t        *table;         // [nchunks][128] chain exit for every entry offset, then [nchunks][2][16][128]: the same and the
-                                 // number of openings for the sixteenths of every chunk (D8_TABLE_BYTES_PER_CHUNK per chunk in all)
+                                 // number of openings for the sixteenths of every chunk (D8_TABLE_BYTES_PER_CHUNK per chunk in all), then
+                                 // [nchunks / 64 + 1][128]: the tables of groups of 64 chunks -- D8_TABLE_BYTES (nchunks)
   uint8_t        *entry;         // [nchunks + 1]
   int64_t        *win_start;     // [nchunks][kD8WinCap]
   uint32_t       *win_count;     // [nchunks]

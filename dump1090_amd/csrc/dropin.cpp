@@ -609,7 +609,7 @@ static bool d8_grow (size_t nsteps, uint32_t nchunks)
       if (p) (void) hipFree (p);
     s.chunks = 0;
     const size_t nw = size_t (nchunks) * kD8WinCap;
-    HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.table), size_t (nchunks) * D8_TABLE_BYTES_PER_CHUNK));
+    HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.table), D8_TABLE_BYTES (nchunks)));
     HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.entry), nchunks + 1));
     HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.win_start), nw * sizeof (int64_t)));
     HIP_OK (hipMalloc (reinterpret_cast<void **> (&s.win_count), nchunks * sizeof (uint32_t)));

@@ -1265,7 +1265,7 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   int rc;
   if ((rc = e->d8_trig.reserve (nwords)) != MODES_OK) return rc;
   if ((rc = e->d8_amb.reserve (nwords)) != MODES_OK) return rc;
-  if ((rc = e->d8_table.reserve (size_t (nchunks) * D8_TABLE_BYTES_PER_CHUNK)) != MODES_OK) return rc;
+  if ((rc = e->d8_table.reserve (D8_TABLE_BYTES (nchunks))) != MODES_OK) return rc;
   if ((rc = e->d8_entry.reserve (nchunks + 1)) != MODES_OK) return rc;
   if ((rc = e->d8_win_start.reserve (size_t (nchunks) * kD8WinCap)) != MODES_OK) return rc;
   if ((rc = e->d8_win_count.reserve (nchunks)) != MODES_OK) return rc;

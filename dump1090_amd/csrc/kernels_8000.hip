@@ -360,11 +360,29 @@ void d8_chain_table_kernel (const D8Params q)
   q.table[size_t (c) * 128 + r] = uint8_t (e);
 }
 
+// The chain through the chunks is one dependent table look-up per chunk.  Groups of kD8Group chunks compose their
+// tables side by side (this kernel), one thread follows the groups' tables (d8_chain_resolve_kernel) and every chunk's
+// workgroup of the walk kernel follows its own group up to itself.
+constexpr int kD8Group = 64;
+__device__ __forceinline__ uint8_t *group_tables (const D8Params &q) { return q.table + size_t (q.nchunks) * D8_TABLE_BYTES_PER_CHUNK; }
+
+__global__ __launch_bounds__ (128)
+void d8_chain_group_kernel (const D8Params q)
+{
+  __shared__ __attribute__ ((aligned (16))) uint8_t tab[kD8Group * 128];
+  const uint32_t c0 = blockIdx.x * kD8Group, n = min (uint32_t (kD8Group), q.nchunks - c0);
+  const uint4 *src = reinterpret_cast<const uint4 *> (q.table + size_t (c0) * 128);
+  for (uint32_t i = threadIdx.x; i < n * 8; i += 128) reinterpret_cast<uint4 *> (tab)[i] = src[i];
+  __syncthreads ();
+  const uint32_t r = threadIdx.x;
+  uint32_t e = r < uint32_t (kD8Net) ? r : 0u;
+  for (uint32_t c = 0; c < n; c++) e = tab[c * 128 + e];
+  group_tables (q)[size_t (blockIdx.x) * 128 + r] = uint8_t (e);
+}
+
 // One thread: what happens before step 0 (a window carried in, triggers among the last steps of the previous
-// call, ref: :493-496 re-scans them), then the entry offset of every chunk.
+// call, ref: :493-496 re-scans them), then the entry offset of every group of chunks (entry[kD8Group * g]).
 // pre[0] = count, pre[1..2] = window starts (< 0) found there.
-// The chain through the chunks is one dependent table look-up per chunk: the workgroup stages 256 chunks' tables in LDS
-// at a time, thread 0 follows them there.
 __global__ __launch_bounds__ (256)
 void d8_chain_resolve_kernel (const D8Params q, u64 trig_tail, long long search0, long long *pre)
 {
@@ -386,13 +404,14 @@ void d8_chain_resolve_kernel (const D8Params q, u64 trig_tail, long long search0
     e = uint32_t (min (pos, (long long) (kD8Net - 1)));
     q.entry[0] = uint8_t (e);
   }
-  for (uint32_t base = 0; base < q.nchunks; base += 256) {
-    const uint32_t n = min (256u, q.nchunks - base);
-    const uint4 *src = reinterpret_cast<const uint4 *> (q.table + size_t (base) * 128);
+  const uint32_t ngroups = (q.nchunks + kD8Group - 1) / kD8Group;
+  for (uint32_t base = 0; base < ngroups; base += 256) {
+    const uint32_t n = min (256u, ngroups - base);
+    const uint4 *src = reinterpret_cast<const uint4 *> (group_tables (q) + size_t (base) * 128);
     for (uint32_t i = threadIdx.x; i < n * 8; i += 256) reinterpret_cast<uint4 *> (tab)[i] = src[i];
     __syncthreads ();
     if (threadIdx.x == 0)
-      for (uint32_t c = 0; c < n; c++) { e = tab[c * 128 + e]; q.entry[base + c + 1] = uint8_t (e); }
+      for (uint32_t g = 0; g < n; g++) { e = tab[g * 128 + e]; if ((base + g + 1) * kD8Group <= q.nchunks) q.entry[(base + g + 1) * kD8Group] = uint8_t (e); }
     __syncthreads ();
   }
 }
@@ -443,13 +462,17 @@ void d8_chain_walk_kernel (const D8Params q, const long long *pre, long long *pe
   __shared__ __attribute__ ((aligned (16))) uint8_t sub_tab[2 * kD8Subs][128];
   uint8_t (*const sub_cnt)[128] = sub_tab + kD8Subs;
   __shared__ int s_entry[kD8Subs], s_off[kD8Subs], s_whole[kD8Subs], s_cut[kD8Subs];
+  __shared__ __attribute__ ((aligned (16))) uint8_t before[(kD8Group - 1) * 128];      // the tables of the chunks of this group in front of this one
   const uint32_t c = blockIdx.x;
+  const uint32_t c_first = c / kD8Group * kD8Group;
   const long long n_lo = (long long) c * kD8ChunkSteps, n_hi = min (n_lo + (long long) kD8ChunkSteps, (long long) q.nsteps);
   const int nwords = int ((n_hi - n_lo + 63) >> 6);
   const int len = int (n_hi - n_lo);
   for (int i = threadIdx.x; i < kD8ChunkSteps / 64; i += kD8WalkThreads) bm[i] = i < nwords ? q.trig[(n_lo >> 6) + i] : 0;
   for (int i = threadIdx.x; i < kD8SubBytes / 16; i += kD8WalkThreads)
     reinterpret_cast<uint4 *> (&sub_tab[0][0])[i] = reinterpret_cast<const uint4 *> (q.table + size_t (q.nchunks) * 128 + size_t (c) * kD8SubBytes)[i];
+  for (uint32_t i = threadIdx.x; i < (c - c_first) * 8; i += kD8WalkThreads)
+    reinterpret_cast<uint4 *> (before)[i] = reinterpret_cast<const uint4 *> (q.table + size_t (c_first) * 128)[i];
   __syncthreads ();
   int64_t *ws = q.win_start + size_t (c) * kD8WinCap;
   if (threadIdx.x == 0) {
@@ -459,7 +482,8 @@ void d8_chain_walk_kernel (const D8Params q, const long long *pre, long long *pe
         const long long s = pre[1 + k];
         if (s + kD8Win <= (long long) q.nsteps) ws[n++] = s; else atomicMin (pending_out, s - (long long) q.nsteps);
       }
-    uint32_t e = q.entry[c];
+    uint32_t e = q.entry[c_first];
+    for (uint32_t cc = 0; cc < c - c_first; cc++) e = before[cc * 128 + e];
     for (int j = 0; j < kD8Subs; j++) { s_entry[j] = int (e); s_off[j] = n; n += sub_cnt[j][e]; e = sub_tab[j][e]; }
   }
   __syncthreads ();
@@ -1009,6 +1033,7 @@ hipError_t launch_d8_chain_exit (const D8Params &q, int32_t *exit_of, hipStream_
 hipError_t launch_d8_chain (const D8Params &q, unsigned long long trig_tail, long long search0, long long *pre,
                             long long *pending_out, hipStream_t stream)
 {
+  if (q.nchunks) hipLaunchKernelGGL (d8_chain_group_kernel, dim3 ((q.nchunks + kD8Group - 1) / kD8Group), dim3 (128), 0, stream, q);
   hipLaunchKernelGGL (d8_chain_resolve_kernel, dim3 (1), dim3 (256), 0, stream, q, (u64) trig_tail, search0, pre);
   if (q.nchunks) hipLaunchKernelGGL (d8_chain_walk_kernel, dim3 (q.nchunks), dim3 (kD8WalkThreads), 0, stream, q, pre, pending_out);
   return hipGetLastError ();

@@ -89,6 +89,12 @@ def test_windows_far_apart_take_a_tile_each():
     check(synth.quantise(x, "uc8"), "uc8", 0)
 
 
+def test_chain_through_more_than_one_group_of_chunks():
+    """The window chain is resolved over groups of 64 chunks of 65536 steps: 40 M samples are 77 chunks, two groups."""
+    iq, _ = synth.capture(2_500_000, 8.0e6, "sc16", seed=93, frames_per_sec=1500, ap_fraction=0.2)
+    check(np.tile(iq, 16), "sc16", 1000)
+
+
 def test_long_recording_runs_in_chunk_ranges():
     """Sixteen chunks and more (8.4 M samples) make the engine walk the windows in four ranges, each range's ordered
     pass on the host overlapping the next range's kernels: the message list must not notice the seams."""
