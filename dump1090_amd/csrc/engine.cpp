@@ -214,7 +214,8 @@ struct modes_engine {
   PinBuf<Record> pin_recs2;
   uint64_t d8_last_chunks = 0, d8_last_nwin = 0, d8_last_nrec = 0, d8_last_msgs = 0;   // the last run: sizes the next run's arrays                  // 8 MS/s: signal sums of the accepted messages, range by range
   std::vector<hipEvent_t> d8_gathered;        // one per range of chunks: its packed windows / records are in pinned memory
-  hipEvent_t d8_chain_done = nullptr, d8_edges_done = nullptr;   // the window list stands / the windows at block edges are done
+  hipEvent_t d8_chain_done = nullptr;
+  std::vector<hipEvent_t> d8_edge_ev;                            // [range]: the range's windows at block edges are done   // the window list stands / the windows at block edges are done
   std::vector<hipEvent_t> d8_events;          // three per range of chunks: windows begin / end, counts (then records) on the host
   unsigned long long *d_stats = nullptr;
   uint32_t cap = 0;
@@ -919,7 +920,7 @@ void modes_engine_destroy (modes_engine *e)
   for (hipEvent_t ev : e->d8_events) if (ev) (void) hipEventDestroy (ev);
   for (hipEvent_t ev : e->d8_gathered) if (ev) (void) hipEventDestroy (ev);
   if (e->d8_chain_done) (void) hipEventDestroy (e->d8_chain_done);
-  if (e->d8_edges_done) (void) hipEventDestroy (e->d8_edges_done);
+  for (hipEvent_t ev : e->d8_edge_ev) (void) hipEventDestroy (ev);
   if (e->tabs.short_tab) (void) hipFree (e->tabs.short_tab);
   if (e->tabs.long_tab) (void) hipFree (e->tabs.long_tab);
   if (e->tabs.lut256) (void) hipFree (e->tabs.lut256);
@@ -1406,7 +1407,11 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
     for (size_t i = have; i < e->d8_events.size (); i++) HIP_TRY (hipEventCreate (&e->d8_events[i]));
   }
   if (!e->d8_chain_done) HIP_TRY (hipEventCreateWithFlags (&e->d8_chain_done, hipEventDisableTiming));
-  if (!e->d8_edges_done) HIP_TRY (hipEventCreateWithFlags (&e->d8_edges_done, hipEventDisableTiming));
+  while (e->d8_edge_ev.size () < nranges) {
+    hipEvent_t ev;
+    HIP_TRY (hipEventCreateWithFlags (&ev, hipEventDisableTiming));
+    e->d8_edge_ev.push_back (ev);
+  }
   while (e->d8_gathered.size () < nranges) {
     hipEvent_t ev;
     HIP_TRY (hipEventCreateWithFlags (&ev, hipEventDisableTiming));
@@ -1438,19 +1443,22 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   if ((rc = e->pin_recs.reserve (size_t (nchunks) * br + 1)) != MODES_OK) return rc;
   if ((rc = e->d8_tot.reserve (4 * size_t (nranges))) != MODES_OK) return rc;
   if ((rc = e->pin_tot.reserve (4 * size_t (nranges))) != MODES_OK) return rc;
-  // the few windows at block edges are slow ones: all of them in one launch, not a tail behind every range
-  // (a few waves that wait a lot: on the second stream, beside the first range's windows)
-  // (a few waves that wait a lot: the first range's in front of its other windows, the rest on the second stream
-  // beside them)
+  // the few windows at block edges are slow ones (a few waves that wait a lot): the first range's in front of its
+  // other windows, every other range's in a launch of its own on the stream of the signal levels beside them (idle
+  // until the first walk is over) -- 0.1-0.2 ms each there, through long before the range's other windows are.  (All of
+  // them in one launch took 0.7-1.3 ms beside the window kernels and the second range waited for it: the host stood
+  // still for 0.6 ms and never made that up.)
   if (!same_windows) {
     q.chunk0 = 0;
     HIP_TRY (launch_d8_windows (q, lo[1], stream, 2));
     if (nranges > 1) {
       HIP_TRY (hipEventRecord (e->d8_chain_done, stream));
       HIP_TRY (hipStreamWaitEvent (lvl, e->d8_chain_done, 0));     // (the stream of the signal levels: idle until the first walk is over)
-      q.chunk0 = lo[1];
-      HIP_TRY (launch_d8_windows (q, nchunks - lo[1], lvl, 2));
-      HIP_TRY (hipEventRecord (e->d8_edges_done, lvl));
+      for (uint32_t r = 1; r < nranges; r++) {
+        q.chunk0 = lo[r];
+        HIP_TRY (launch_d8_windows (q, lo[r + 1] - lo[r], lvl, 2));
+        HIP_TRY (hipEventRecord (e->d8_edge_ev[r], lvl));
+      }
     }
   }
   for (uint32_t r = 0; r < nranges; r++) {
@@ -1464,7 +1472,7 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
     // windows of range r + 1 have announced by the time it runs: a record more is kept now and then (its address is not
     // in the cache when the walk gets there, so it changes nothing but `candidates`).
     HIP_TRY (hipStreamWaitEvent (side, e->d8_events[3 * r + 1], 0));
-    if (r == 1 && !same_windows) HIP_TRY (hipStreamWaitEvent (side, e->d8_edges_done, 0));
+    if (r >= 1 && !same_windows) HIP_TRY (hipStreamWaitEvent (side, e->d8_edge_ev[r], 0));
     HIP_TRY (launch_d8_count (q, n, e->d8_chunk_rec.p, side));
     HIP_TRY (launch_d8_offsets (e->d8_chunk_rec.p, e->d8_win_count.p, nchunks, c0, n, e->d8_off.p, e->d8_off.p + nchunks + 1,
                                 uint64_t (n) * bw, uint64_t (n) * br, e->d8_tot.p + 4 * r, e->pin_tot.p + 4 * r, side));
