@@ -53,8 +53,10 @@ static int      g_tables_ready;
 static uint16_t *g_mag_lut, *g_log10_lut;
 static const einfo NO_ERRORS = { 0, 0, { 0, 0 } };
 
+static void global_tables_init (void);
+
 /* ref: src/crc.c:67-82 */
-uint32_t orc_crc_checksum (const uint8_t *msg, int bits)
+static uint32_t crc_checksum_with_table (const uint8_t *msg, int bits)
 {
   uint32_t rem = 0;
   int n = bits / 8, i;
@@ -63,6 +65,12 @@ uint32_t orc_crc_checksum (const uint8_t *msg, int bits)
     rem &= 0xFFFFFF;
   }
   return rem ^ ((uint32_t)msg[n-3] << 16) ^ ((uint32_t)msg[n-2] << 8) ^ msg[n-1];
+}
+/* callable first: the reference builds its table in crc_init() (ref: src/crc.c:281) */
+uint32_t orc_crc_checksum (const uint8_t *msg, int bits)
+{
+  global_tables_init ();
+  return crc_checksum_with_table (msg, bits);
 }
 
 /* ref: src/crc.c:37-62 (poly 0xFFF409) and src/dump1090.c:385-423 (LUTs) */
@@ -80,7 +88,7 @@ static void global_tables_init (void)
   memset (one, 0, sizeof one);
   for (i = 0; i < LONG_BITS; i++) {
     one[i >> 3] = (uint8_t)(1 << (7 - (i & 7)));
-    g_single_bit[i] = orc_crc_checksum (one, LONG_BITS);
+    g_single_bit[i] = crc_checksum_with_table (one, LONG_BITS);
     one[i >> 3] = 0;
   }
   g_mag_lut = calloc (129 * 129, sizeof (uint16_t));
@@ -1426,6 +1434,9 @@ void orc_demod_8000 (orc_ctx *c, const orc_mag_buf *mag)
 
     {                                                   /* window complete (ref: :331-497) */
       int best_result = -1, nbytes = SHORT_BYTES, pass, position, dptr;
+      /* peak_short / peak_long: the reference keeps short_msg_offset / long_msg_offset across the windows of a call
+       * (ref: :153-154) and pick_peak only assigns on `>=` against maxima that start at 0 (ref: :536-551); match[]
+       * holds sums of abs() values, so i = 0 always assigns and the carried values are never read. */
       int peak_short = 0, peak_long = 0, max0 = 0, max1 = 0;
       window = 0;
       for (i = 0; i < D8M_WIN_LEN - SHORT_BITS; i++) {  /* pick_peak, ref: :529-553 */

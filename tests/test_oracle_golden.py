@@ -12,6 +12,7 @@ from oracle import orc
 from conftest import GOLDEN
 
 REC = json.load(open(os.path.join(GOLDEN, "reference_recorded.json")))
+VEC = json.load(open(os.path.join(GOLDEN, "reference_vectors.json")))
 
 
 def test_crc_tables_and_kats():
@@ -154,6 +155,31 @@ def test_frames_js_manchester_slicer():
                 assert orc.crc_checksum(m[:7], 56) & 0xFFFF80 == 0
     assert tot["Decoded with good CRC"] == 108 and hit["Decoded with good CRC"] == 106
     assert hit["Demodulated with 0 errors"] == 86
+    # The two good-CRC frames plain slicing does not reproduce, and why (the dump holds the magnitudes the demodulator
+    # STARTED from and the bytes it ended with):
+    #  * record 15, DF11 5f47ac0217da17: data bit 54 has two equal samples (2160, 2160).  The slicer that wrote the file
+    #    copied the previous bit there (1); today's demod_2000 slices 0 and counts an error (ref: src/demod-2000.c:805-836),
+    #    which is what the oracle does: syndrome 000002, i.e. exactly that bit.
+    #  * record 37, DF20 a0200135ca78a3...: data bit 96 reads 3319 > 3240, a clear 1; the file has 0 and the address
+    #    47ac02 of record 15's aircraft as its syndrome: the bytes come from a phase-corrected retry, the magnitudes
+    #    dumped beside them are the uncorrected ones.
+    miss = []
+    for k, r in enumerate(recs):
+        if r["descr"] != "Decoded with good CRC":
+            continue
+        mag = np.array(r["mag"], dtype=np.uint16)
+        pre = mag[5:].copy()
+        msg = np.zeros(14, dtype=np.uint8)
+        e = C.c_int()
+        L.orc_slice_2000(C.c_void_p(pre.ctypes.data), C.c_void_p(pre.ctypes.data + 32), C.c_void_p(msg.ctypes.data), C.byref(e))
+        nb = r["bits"] // 8
+        exp = bytes.fromhex(r["hex"])[:nb]
+        if bytes(msg)[:nb] != exp:
+            bits = [i for i in range(nb * 8) if ((msg[i // 8] ^ exp[i // 8]) >> (7 - i % 8)) & 1]
+            miss.append((k, bits, int(pre[16 + 2 * bits[0]]), int(pre[16 + 2 * bits[0] + 1]), e.value))
+    assert miss == [(15, [54], 2160, 2160, 1), (37, [96], 3319, 3240, 0)]
+    assert orc.crc_checksum(bytes.fromhex("5f47ac0217da15"), 56) == 0x000002
+    assert orc.crc_checksum(bytes.fromhex(recs[37]["hex"]), 112) == 0x47AC02
 
 
 def test_strip_fixed_point_modes1(modes1):
@@ -183,3 +209,76 @@ def test_field_decode_readme_pair():
     assert f[0]["capa"] == 5 and f[0]["addr"] == 0x4D2023 and f[0]["AC_flags"] & 0x4 and not f[0]["AC_flags"] & 0x2
     assert f[1]["flight_status"] == 0 and f[1]["altitude"] == 23375 and f[1]["unit"] == 1 and f[1]["addr"] == 0x4D2023
     assert f[1]["AC_flags"] & 0x1 and f[1]["AC_flags"] & 0x80000
+
+
+def test_crc_checksum_needs_no_earlier_call():
+    """orc_crc_checksum builds its table itself: a fresh process that calls it first gets the real syndrome."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from oracle import orc; "
+            "print('%%06x' %% orc.crc_checksum(bytes.fromhex('8d479e84580fd03d66d139c1cd17'), 112), "
+            "'%%06x' %% orc.crc_checksum(bytes.fromhex('20000f1f684a6c'), 56))" % os.path.dirname(GOLDEN.rstrip("/")).rsplit("/tests", 1)[0])
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["000000", "4d2023"]
+
+
+def test_reference_held_frames_crc():
+    """Every complete frame the reference's README, tools and sources print: 112-bit CRC (and the two 56-bit ones)."""
+    assert len(VEC["frames_112"]) == 6
+    for f in VEC["frames_112"]:
+        m = bytes.fromhex(f["hex"])
+        assert len(m) == 14 and m[0] >> 3 == 17
+        assert orc.crc_checksum(m, 112) == 0, f
+    for f in VEC["frames_56"]:
+        assert "%06x" % orc.crc_checksum(bytes.fromhex(f["hex"]), 56) == f["syndrome"]
+    # one flipped bit anywhere behind the DF field of a reference-held frame is diagnosed and repaired (ref: src/crc.c:314-352)
+    o = orc.Oracle(fix_bits=1)
+    m = bytearray(bytes.fromhex(VEC["frames_112"][0]["hex"]))
+    for bit in (5, 40, 87, 111):
+        m[bit // 8] ^= 0x80 >> (bit % 8)
+        assert o.diagnose(orc.crc_checksum(bytes(m), 112), 112) == (1, bit, -1)
+        m[bit // 8] ^= 0x80 >> (bit % 8)
+
+
+def test_reference_held_messages_score_and_decode():
+    """The same frames through the oracle's modeS_message_score / decode_mode_S_message: DF17 with syndrome 0 scores
+    1400 while its address is unknown and 1800 once it is known (ref: src/dump1090.c:3247-3268,3339-3341); it is
+    accepted with no error bits and its address enters the ICAO cache (ref: src/dump1090.c:2676-2687)."""
+    o = orc.Oracle(fix_bits=1)
+    for f in VEC["frames_112"]:
+        m = bytes.fromhex(f["hex"])
+        addr = int(f["hex"][2:8], 16)
+        assert o.score(m, 112) == (1800 if o.icao_test(addr) else 1400)
+        rc, out = o.decode(m)
+        assert rc >= 0 and o.icao_test(addr) and o.score(m, 112) == 1800
+        assert int(out["msg_type"]) == 17 and int(out["error_bits"]) == 0 and int(out["msg_bits"]) == 112
+        assert int(out["addr"]) == int(f["hex"][2:8], 16)
+        if "icao" in f:
+            assert "%06x" % int(out["addr"]) == f["icao"]
+
+
+def vec_df17_message():
+    d = VEC["decode_df17"]
+    m = np.zeros(1, dtype=orc.MSG_DTYPE)
+    b = bytes.fromhex(d["hex"])
+    m[0]["msg"][:14] = np.frombuffer(b, dtype=np.uint8)
+    m[0]["msg_type"], m[0]["crc"], m[0]["msg_bits"] = d["df"], 0, 112
+    return d, m
+
+
+def check_df17_fields(d, f, msg):
+    """What the reference prints for this message (README.md:143-155)."""
+    assert f["capa"] == d["capability"] and "%06x" % f["addr"] == d["icao"]
+    assert f["ME_type"] == d["me_type"] and f["ME_subtype"] == d["me_subtype"]
+    assert f["altitude"] == d["altitude_feet"] and f["unit"] == 1 and f["AC_flags"] & 0x1          # MODES_ACFLAGS_ALTITUDE_VALID, feet
+    assert f["raw_latitude"] == d["raw_latitude"] and f["raw_longitude"] == d["raw_longitude"]
+    assert bool(f["AC_flags"] & 0x08) == (d["f_flag"] == "even") and not f["AC_flags"] & 0x10       # LLEVEN_VALID, not LLODD_VALID
+    assert ((msg[6] >> 3) & 1 == 0) == (d["t_flag"] == "non-UTC")                                  # the T bit itself (ME bit 21)
+
+
+def test_field_decode_readme_df17():
+    """README.md:143-155 of the reference: the only extended-squitter decode it prints."""
+    d, m = vec_df17_message()
+    assert "%06x" % (int.from_bytes(bytes(m[0]["msg"][11:14]), "big")) == d["crc_printed"]
+    f = orc.decode_fields(m)
+    check_df17_fields(d, f[0], m[0]["msg"])
