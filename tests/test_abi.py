@@ -78,4 +78,14 @@ def test_crc_entry_points_match_oracle():
         L.crc_checksum_fix(m.ctypes.data_as(C.c_void_p), ei)
         assert bytes(m).hex().upper() == "8D4840D6202CC371C32CE0576098"
     assert L.crc_checksum_diagnose(0, 112).contents.errors == 0
+    # the frames the reference itself prints (tests/golden/reference_vectors.json: README.md, tools/SBS_client.py)
+    import json, os
+    from conftest import GOLDEN
+    vec = json.load(open(os.path.join(GOLDEN, "reference_vectors.json")))
+    for f in vec["frames_112"]:
+        m = np.frombuffer(bytes.fromhex(f["hex"]), dtype=np.uint8).copy()
+        assert L.crc_checksum(m.ctypes.data_as(C.c_void_p), 112) == 0
+    for f in vec["frames_56"]:
+        m = np.frombuffer(bytes.fromhex(f["hex"]), dtype=np.uint8).copy()
+        assert "%06x" % L.crc_checksum(m.ctypes.data_as(C.c_void_p), 56) == f["syndrome"]
     L.crc_exit()
