@@ -143,6 +143,7 @@ def lib():
         L.modes_engine_time_scan.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p,
                                              C.POINTER(C.c_float)]
         L.modes_engine_rerun_accept.argtypes = [C.c_void_p, C.c_void_p]
+        L.modes_engine_can_rerun_accept.argtypes = [C.c_void_p]
         L.modes_engine_get_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.modes_engine_get_power_stats.argtypes = [C.c_void_p, C.POINTER(PowerStats)]
         L.modes_engine_set_d8_state.argtypes = [C.c_void_p, C.POINTER(D8State)]
@@ -263,6 +264,10 @@ class Engine:
     def rerun_accept(self, stream=None):
         """Repeat only the ordered accept pass + emit of the last run (after set_icao)."""
         _check(self.L.modes_engine_rerun_accept(self.h, C.c_void_p(stream) if stream else None))
+
+    def can_rerun_accept(self):
+        """False for engines whose ordered pass is not on the device (mode_ac, phase_enhance, host_replay) or with no run yet."""
+        return bool(self.L.modes_engine_can_rerun_accept(self.h))
 
     def counters(self):
         a, b = C.c_uint64(), C.c_uint64()

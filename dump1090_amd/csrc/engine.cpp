@@ -1728,6 +1728,8 @@ int modes_engine_rerun_accept (modes_engine *e, void *stream_v)
   return run_accept_on_device (e, e->last_sp, e->last_first_sample, stream, false);
 }
 
+int modes_engine_can_rerun_accept (const modes_engine *e) { return e && e->have_scan && !e->cfg.mode_ac; }
+
 int modes_engine_d8_chain_map (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t first_sample, const uint16_t *d_halo,
                                void *stream_v, int32_t *map)
 {
@@ -1780,12 +1782,22 @@ int modes_engine_get_d8_state (modes_engine *e, modes_d8_state *out, int want_ac
     q.p0 = e->d8_p0.p; q.mx = e->d8_mx.p; q.write_arrays = 1;
     // d8_trig_kernel counts ambiguous steps into amb_count and rewrites the trigger words without the decisions the
     // running average added: both are restored by the acc kernel walking the whole shard (it ORs the same bits back)
-    if (e->d8_limit < q.nsteps) HIP_TRY (launch_d8_trig (q, 0, stream));
+    // While the planes are being rewritten they are nobody's to reuse (modes_engine_d8_reuse_planes): a failure on the
+    // way leaves them marked invalid, and the next run forms them again.
+    const bool planes_were_valid = e->d8_planes_valid;
+    e->d8_planes_valid = false;
+    if (e->d8_limit < q.nsteps) {
+      // the relaunch counts the ambiguous steps again: start the count from zero, so a run that reuses the planes
+      // reports them once (modes_d8_state.amb_steps)
+      HIP_TRY (hipMemsetAsync (q.amb_count, 0, sizeof (uint32_t), stream));
+      HIP_TRY (launch_d8_trig (q, 0, stream));
+    }
     int32_t *d_acc = reinterpret_cast<int32_t *> (e->d8_small.p + 7);
     HIP_TRY (launch_d8_acc (q, q.nsteps, d_acc, stream));
     int32_t acc = 0;
     HIP_TRY (hipMemcpyAsync (&acc, d_acc, sizeof acc, hipMemcpyDeviceToHost, stream));
     HIP_TRY (hipStreamSynchronize (stream));
+    e->d8_planes_valid = planes_were_valid;
     e->d8_out.acc = acc; e->d8_out.acc_valid = 1;
     e->d8_out_acc_valid = true;
   }

@@ -89,7 +89,10 @@ bool decode_block (modes_live *l, const modes_live::Slot &s, std::vector<modes_m
     modes_message x = m[i];
     x.block = l->block_index;
     // mm.sys_timestamp_msg = block's system time + receiveclock_ms_elapsed (ref: src/demod-2400.c:470-472, src/misc.c:1259-1262)
-    x.reserved = uint32_t (s.sys_ms + int64_t ((x.timestamp - block_ts) / 12000));
+    // (signed throughout, like the reference's int64_t receiveclock_ms_elapsed: demod_8000 can stamp a message in front of
+    // its block; a block taken in within its own duration of modes_live_open starts at 0, not before it)
+    const int64_t at_ms = s.sys_ms + (int64_t (x.timestamp) - int64_t (block_ts)) / 12000;
+    x.reserved = uint32_t (at_ms < 0 ? 0 : at_ms);
     found.push_back (x);
   }
   l->block_index++;
@@ -171,6 +174,7 @@ void modes_live_close (modes_live *l)
     l->stop = true; l->hold = false;
   }
   l->cv_work.notify_all ();
+  l->cv_idle.notify_all ();                       // a flush that waits on another thread gives up
   if (l->worker.joinable ()) l->worker.join ();
   for (auto &s : l->slots) if (s.pin) (void) hipHostFree (s.pin);
   if (l->d_block) (void) hipFree (l->d_block);
@@ -208,6 +212,7 @@ int modes_live_rx (modes_live *l, const void *iq, uint32_t len)
     s.counter = l->sample_counter;
     l->sample_counter += samples_read;
     s.sys_ms = now_ms (l) - int64_t ((1E3 * samples_read) / l->cfg.sample_rate);
+    if (s.sys_ms < 0) s.sys_ms = 0;
     if (to_convert * l->bps > l->max_bytes) {                      // "how did that happen?": the excess counts as dropped
       to_convert = l->max_bytes / l->bps;
       l->dropped = samples_read - to_convert;
@@ -246,8 +251,10 @@ int modes_live_flush (modes_live *l)
 {
   if (!l) return set_error (MODES_E_ARG, "null argument");
   std::unique_lock<std::mutex> lk (l->mu);
-  l->cv_idle.wait (lk, [&] { return l->failed || (l->queued.empty () && !l->busy); });
+  // on hold the worker leaves the queue alone: wait for the block in progress only, and say that blocks are still queued
+  l->cv_idle.wait (lk, [&] { return l->failed || l->stop || (!l->busy && (l->hold || l->queued.empty ())); });
   if (l->failed) return set_error (MODES_E_HIP, "modes_live: the decoder failed: %s", l->error.c_str ());
+  if (!l->queued.empty ()) return set_error (MODES_E_ARG, "modes_live_flush: %zu blocks are still queued (the worker is on hold or stopping)", l->queued.size ());
   return MODES_OK;
 }
 

@@ -14,7 +14,7 @@ stream before it:
 (b) and (c) are resolved the way the blocks inside a shard are: decode with a guess, exchange what the shards end with
 (a few KiB each), decode again from the neighbour's exit state, stop when no entry state changes.  Decisions only depend
 on earlier positions, so the fixed point is the sequential result; it is reached after at most `world` rounds, in
-practice two.  At 2.0 / 2.4 MS/s the scan kernel's records do not depend on the cache, so rounds after the first
+practice two at any world size (`next_entries`: every rank sees every exit and composes them).  At 2.0 / 2.4 MS/s the scan kernel's records do not depend on the cache, so rounds after the first
 repeat only the ordered accept pass (`modes_engine_rerun_accept`).  No data-path collective: only the states and
 the (small) message lists travel.
 """
@@ -55,6 +55,39 @@ def _same(a, b):
     return a == b
 
 
+def _icao_of(state):
+    return state["icao"] if isinstance(state, dict) else state
+
+
+def _with_icao(state, icao):
+    if isinstance(state, dict):
+        out = dict(state)
+        out["icao"] = icao
+        return out
+    return icao
+
+
+def next_entries(entered, exits):
+    """The entry states of the next round, for every rank, from what every rank entered with and left with in this one.
+
+    Rank j's entry is rank j - 1's exit.  Handing the exits on one rank per round would carry an address heard in shard
+    0 to shard 7 in seven rounds; but every rank sees every exit, and a shard's exit cache is its entry cache with the
+    slots it wrote itself replaced (ref: src/dump1090.c:1455-1461: a slot is overwritten, never merged).  So the exit
+    rank j - 1 WOULD have left, had it been entered with the new entry, is predicted as: the slots it wrote (where its
+    exit differs from what it entered with) from its exit, every other slot passed through from its new entry.  The
+    prediction is only a guess for the next round -- the loop still ends only when every rank's entry IS its
+    neighbour's exit -- but it is exact whenever a shard's own writes do not depend on its entry cache (only clean
+    DF11/17/18 write, ref: src/dump1090.c:2676-2687), which makes two rounds the rule at any world size.  A rank whose
+    predecessors are all settled gets its predecessor's exit unchanged, so at most `world` rounds are needed as before.
+    Anything else a state carries (demod_8000's "d8") is taken from the neighbour's exit as it is."""
+    out = [entered[0]]
+    for j in range(1, len(entered)):
+        wrote = _icao_of(exits[j - 1]) != _icao_of(entered[j - 1])
+        icao = np.where(wrote, _icao_of(exits[j - 1]), _icao_of(out[j - 1])).astype(np.uint32)
+        out.append(_with_icao(exits[j - 1], icao))
+    return out
+
+
 def decode_sharded(decode, rank, world, all_gather, initial_icao=None, max_rounds=None, initial_state=None):
     """Runs `decode(entry_state) -> (messages, exit_state)` for this rank's shard until the entry states of all ranks
     are consistent.  A state is the ICAO cache (uint32[1024]) or a dict of named parts (compared part by part).
@@ -67,7 +100,8 @@ def decode_sharded(decode, rank, world, all_gather, initial_icao=None, max_round
         entry = initial_state
     else:
         entry = guess if initial_icao is None or rank > 0 else np.asarray(initial_icao, dtype=np.uint32)
-    entered = [guess] * world                    # what every rank decoded from in this round (rank 0's never changes)
+    first = guess if (initial_state is not None or initial_icao is None) else np.asarray(initial_icao, dtype=np.uint32)
+    entered = [first] + [guess] * (world - 1)   # what every rank decoded from in this round (rank 0's never changes)
     rounds = 0
     msgs = exit_state = None
     fresh = True
@@ -81,10 +115,9 @@ def decode_sharded(decode, rank, world, all_gather, initial_icao=None, max_round
             return msgs, rounds
         if max_rounds is not None and rounds >= max_rounds:
             raise RuntimeError("state hand-over did not settle in %d rounds" % rounds)
-        new_entry = entry if rank == 0 else exits[rank - 1]
-        fresh = not _same(new_entry, entry)
-        entry = new_entry
-        entered = [entered[0]] + [exits[j - 1] for j in range(1, world)]
+        entered = next_entries(entered, exits)
+        fresh = not _same(entered[rank], entry)
+        entry = entered[rank]
 
 
 def merge(per_rank_messages):
@@ -257,7 +290,9 @@ class EngineShard:
         e = self.e
         self.rounds += 1
         e.set_icao(entry["icao"])
-        if self.rate != 8000000 and self.scanned and self.count:
+        # (engines that keep their ordered pass on the host -- mode_ac, phase_enhance, host_replay -- cannot repeat the
+        # accept pass alone: they decode the shard again, on every rank alike, so no rank is left waiting in a collective)
+        if self.rate != 8000000 and self.scanned and self.count and e.can_rerun_accept():
             e.rerun_accept(stream=self.stream)                       # the scan's records do not depend on the cache
         else:
             halo = None
@@ -345,15 +380,15 @@ def decode_engine_rounds(shard, rank, world, all_gather, max_rounds=None):
             asked = asked or bool(st.amb_steps)
             st.amb_steps = 0
             exits.append({"icao": g["icao"], "d8": bytes(st)})
-        if max_rounds is not None and rounds >= max_rounds + 1:
-            raise RuntimeError("state hand-over did not settle in %d rounds" % rounds)
         if asked and not need_acc:
             need_acc = True                      # the states just exchanged lack the average: exchange again, with it
             fresh = False
+            rounds -= 1                          # ... which decodes nothing and is no round of the budget
             continue
         if all(_same(exits[j - 1], entered[j]) for j in range(1, world)):
             return rounds
-        new_entry = entry if rank == 0 else exits[rank - 1]
-        fresh = not _same(new_entry, entry)
-        entry = new_entry
-        entered = [entered[0]] + [exits[j - 1] for j in range(1, world)]
+        if max_rounds is not None and rounds >= max_rounds:
+            raise RuntimeError("state hand-over did not settle in %d rounds" % rounds)
+        entered = next_entries(entered, exits)
+        fresh = not _same(entered[rank], entry)
+        entry = entered[rank]

@@ -235,6 +235,9 @@ int  modes_engine_format_raw (modes_engine *e, int upper_case, const char **text
  * and the emit of the LAST run (2.0 / 2.4 MS/s, ordered pass on the device, no mode_ac; the run's d_iq must still be
  * valid: the signal level is read from it).  Results replace those of the last run. */
 int  modes_engine_rerun_accept (modes_engine *e, void *stream);
+/* 1 when modes_engine_rerun_accept() would be accepted for the last run, 0 when the shard has to be decoded again with
+ * modes_engine_run_device() (mode_ac, phase_enhance and host_replay engines, 8 MS/s, or no successful run yet) */
+int  modes_engine_can_rerun_accept (const modes_engine *e);
 /* scan kernel launches and ordered passes since the engine was created */
 int  modes_engine_get_counters (const modes_engine *e, uint64_t *scan_launches, uint64_t *accept_passes);
 

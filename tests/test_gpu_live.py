@@ -95,6 +95,8 @@ def test_dropped_blocks_and_discontinuity():
     live.hold(True)
     results = [live.rx(b) for b in blocks[1:5]]        # two fit the ring, two are dropped
     assert results == [1, 1, 0, 0]
+    with pytest.raises(da.ModesError):                 # on hold the queue is left alone: flush says so instead of waiting for ever
+        live.flush()
     live.hold(False)
     live.flush()
     assert live.rx(blocks[5]) == 1                     # discontinuous: behind the drop

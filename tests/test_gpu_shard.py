@@ -194,6 +194,32 @@ def test_engine_shards_reach_the_single_pass_result(rate, fmt, world):
             assert sh.entry_states is None        # near-silent input: the trigger needs the running average, rounds find the states
 
 
+@pytest.mark.parametrize("kw", [{"phase_enhance": True}, {"mode_ac": True}, {"host_replay": True}])
+def test_shards_of_engines_that_cannot_repeat_the_accept_pass_alone(kw):
+    """Engines whose ordered pass is on the host (phase_enhance, host_replay) or that run a second demodulator per block
+    (mode_ac) refuse modes_engine_rerun_accept: their shards are decoded again in the hand-over rounds -- on every rank,
+    so none is left waiting in the collective -- and still reach the single-pass result."""
+    rate, world = 2400000, 3
+    iq, _ = synth.capture(65536 * 7 + 4321, float(rate), "sc16", seed=98, frames_per_sec=2500, ap_fraction=0.5, n_icao=6, bitflip1=0.2)
+    exp, _ = oracle_run(iq, "sc16", rate=rate, phase_enhance=bool(kw.get("phase_enhance")), also_ac=bool(kw.get("mode_ac")))
+    raw = np.ascontiguousarray(iq).view(np.uint8)
+    plan = shard.plan_shards(raw.size // 4, 65536, world)
+    held = []
+
+    def make_shard(r):
+        first, count = plan[r]
+        lead = 65536 if first else 0
+        buf = torch.from_numpy(raw[(first - lead) * 4:(first + count) * 4].copy()).to("cuda:0")
+        held.append(buf)
+        return shard.EngineShard(da.Engine(rate, da.INPUT_SC16, fix_bits=1, **kw), buf.data_ptr(), buf.numel(), lead, first, count, rate, 4)
+    res = _run_ranks(world, make_shard)
+    assert_same_messages(shard.merge([m for m, _, _ in res]), exp)
+    assert (np.isin(exp["msg_type"], (0, 4, 5, 16, 20, 21))).sum() > 100 and res[0][1] >= 2
+    for _, _, sh in res:
+        assert not sh.e.can_rerun_accept()
+        assert sh.e.counters()["scan_launches"] >= sh.rounds          # a scan per round: nothing was repeated half-way
+
+
 def test_torch_group_over_rccl_single_rank():
     """The collective path bench.py --gpus N uses (backend "nccl" = RCCL, device tensors, pinned staging) with the one
     rank a one-GPU box allows: states, flags and arrays come back as they went in."""
