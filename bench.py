@@ -40,6 +40,9 @@ import dump1090_amd as da                     # noqa: E402
 from dump1090_amd import synth_torch          # noqa: E402
 
 HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8 TB/s spec
+PMC_HBM_FILES = ("r03_pmc_hbm.json", "r02_pmc_hbm.json")      # newest first (profiles/README.md)
+VALU_ISSUE_CYCLES = 4.0                       # what a wave64 VALU instruction of this kernel's mix holds a SIMD for (see valu_issue below)
+PMC_STAGE_FILES = ("r03_pmc_scan_stages.json", "r02_pmc_scan_stages.json")
 
 WORKLOADS = {
     #               rate      fmt     engine kwargs                       traffic              kernel
@@ -58,18 +61,89 @@ CONV_ROW = {("uc8", False): 0, ("uc8", True): 1, ("sc16", False): 3, ("sc16", Tr
 
 
 _CPU_WORKER = """
+# One shard of ONE stream on one host core (test infrastructure: the oracle).  Protocol on stdin/stdout, binary: the parent
+# sends the ICAO cache the shard is entered with (4096 bytes), the worker decodes and answers with the cache it leaves
+# (4096 bytes) and its message count (8 bytes); an empty read ends it.
 import sys, numpy as np
 sys.path.insert(0, %r)
 from oracle import orc
-path, rate, fmt, fix_bits, power, dc, also_ac = sys.argv[1], int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7])
-host = np.load(path, mmap_mode="r")
-host = np.ascontiguousarray(host)
-sys.stdout.write("ready\\n"); sys.stdout.flush()
-sys.stdin.readline()
-o = orc.Oracle(rate, fix_bits=fix_bits, measure_noise=bool(power))
-o.run_stream(host, orc.INPUT_UC8 if fmt == "uc8" else orc.INPUT_SC16, rate // 1000, compute_power=bool(power), filter_dc=bool(dc), also_ac=bool(also_ac))
-sys.stdout.write("done %%d\\n" %% len(o.messages())); sys.stdout.flush()
+path, rate, fmt, fix_bits, power, also_ac, rank, world = sys.argv[1], int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7]), int(sys.argv[8])
+raw = np.load(path, mmap_mode="r")
+bps = 2 if fmt == "uc8" else 4
+B = 262144 // bps
+nblk = raw.nbytes // 262144
+base, extra = divmod(nblk, world)
+b0 = rank * base + min(rank, extra)
+nb = base + (1 if rank < extra else 0)
+mine = np.ascontiguousarray(raw[b0 * 262144 // raw.itemsize: (b0 + nb) * 262144 // raw.itemsize])
+ov = int((8 + 112 + 16) * 1e-6 * rate)
+ifmt = orc.INPUT_UC8 if fmt == "uc8" else orc.INPUT_SC16
+tail = None
+if b0:      # the magnitudes in front of the shard: the converter over the block before it (a pure function of the samples)
+    prev = np.ascontiguousarray(raw[(b0 - 1) * 262144 // raw.itemsize: b0 * 262144 // raw.itemsize])
+    tail = orc.convert(orc.convert_select(ifmt, False, bool(power)), prev, B, sample_rate=float(rate))[0][B - ov:]
+out, inp = sys.stdout.buffer, sys.stdin.buffer
+out.write(b"ready\\n"); out.flush()
+while True:
+    blob = inp.read(4096)
+    if len(blob) < 4096:
+        break
+    o = orc.Oracle(rate, fix_bits=fix_bits, measure_noise=bool(power))
+    o.icao_import(np.frombuffer(blob, dtype=np.uint32))
+    o.stream_start(b0 * B, tail)
+    if nb:
+        o.run_stream(mine, ifmt, rate // 1000, compute_power=bool(power), also_ac=bool(also_ac))
+    out.write(o.icao_export().tobytes() + np.array([len(o.messages())], dtype=np.int64).tobytes()); out.flush()
 """ % ROOT
+
+
+def cpu_all_cores(host, rate, fmt, bps, fix_bits, power, also_ac, single_msgs):
+    """The oracle on ONE stream over all host cores: the sample is cut into one shard of whole blocks per core, every
+    shard is decoded by its own process, and the ICAO caches are handed from shard to shard until no entry moves
+    (dump1090_amd.shard.next_entries -- what the GPU ranks do).  Wall time covers every round.  Fresh interpreter
+    processes (no torch, no HIP): nothing of this process's GPU state is forked."""
+    import subprocess
+    import tempfile
+    from dump1090_amd import shard as shard_mod
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+        path = os.path.join(td, "sample.npy")
+        np.save(path, host)
+        argv = [sys.executable, "-c", _CPU_WORKER, path, str(rate), fmt, str(fix_bits), str(int(power)), str(int(also_ac))]
+        procs = [subprocess.Popen(argv + [str(r), str(cores)], stdin=subprocess.PIPE, stdout=subprocess.PIPE) for r in range(cores)]
+        try:
+            for pr in procs:
+                assert pr.stdout.readline().strip() == b"ready"
+            zero = np.zeros(1024, dtype=np.uint32)
+            entered = [zero] * cores
+            todo = list(range(cores))
+            exits, counts = [None] * cores, [0] * cores
+            rounds = decodes = 0
+            t0 = time.perf_counter()
+            while True:
+                for r in todo:
+                    procs[r].stdin.write(entered[r].tobytes()); procs[r].stdin.flush()
+                for r in todo:
+                    blob = procs[r].stdout.read(4096 + 8)
+                    exits[r] = np.frombuffer(blob[:4096], dtype=np.uint32).copy()
+                    counts[r] = int(np.frombuffer(blob[4096:], dtype=np.int64)[0])
+                rounds += 1
+                decodes += len(todo)
+                if all(np.array_equal(exits[j - 1], entered[j]) for j in range(1, cores)) or rounds > cores + 1:
+                    break
+                nxt = shard_mod.next_entries(entered, exits)
+                todo = [r for r in range(cores) if not np.array_equal(nxt[r], entered[r])]
+                entered = nxt
+            adt = time.perf_counter() - t0
+        finally:
+            for pr in procs:
+                pr.stdin.close()
+            for pr in procs:
+                pr.wait()
+    return {"value": round(host.nbytes // bps / adt / 1e6, 2), "unit": "Msamples/s", "cores": cores, "rounds": rounds,
+            "shard_decodes": decodes, "msgs": int(sum(counts)), "msgs_equal_single_thread": int(sum(counts)) == int(single_msgs),
+            "sample": "the same %d MiB as ONE stream cut into %d shards of whole blocks, one oracle process per core, ICAO caches "
+                      "handed over to a fixed point (all rounds timed)" % (host.nbytes >> 20, cores)}
 
 
 def _same_messages(g, c):
@@ -241,32 +315,53 @@ def run_workload(name, args, world, rank, local, dev, want_cpu):
 
     # dominant kernel: HIP events on the launch stream around it, averaged over the timed steps
     kernel_ms = kms / args.steps / nrec                           # per recording (a long shard's scan is up to four launches: their sum)
+    if rate == 8000000:
+        # demod_8000 is two kernels that each read every sample (trigger planes, then the match windows): the pipeline's
+        # roofline figure is the algorithmic bytes over BOTH (the window kernel alone would flatter it)
+        kernel = "d8_trig_kernel + d8_window_kernel"
+        kernel_ms += k2 / args.steps / nrec
     # algorithmic bytes per sample: the IQ bytes the selected converter has to read
     alg_bps = 1 if (fmt == "uc8" and not power) else bps
     achieved = nsamples * alg_bps / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    traffic = args.traffic
-    if traffic is None and args.gib == 4.0 and nrec == 1:
-        # HBM bytes per launch of the scan kernel from the committed PMC passes (profiles/README.md), same size and seed
-        try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_hbm.json")) as f:
-                traffic = json.load(f).get(name, {}).get("traffic_bytes_per_step")
-        except (OSError, ValueError):
-            traffic = None
+    # HBM bytes per step of the dominant kernel from PMC counters.  The counters cannot be read inside this process
+    # (rocprofv3 collects them in passes of their own): the number is the one of the committed pass over THIS command
+    # (profiles/README.md), valid only for the same recording -- same size, same seed, one rank -- and null otherwise.
+    traffic, traffic_note = args.traffic, "--traffic"
+    if traffic is None:
+        if args.gib != 4.0 or world != 1 or nrec != 1:
+            traffic_note = "null: the committed PMC pass covers the 4 GiB single-GPU recording of seed 1, not this run"
+        else:
+            traffic_note = "null: no committed PMC pass for this workload"
+            for src in PMC_HBM_FILES:
+                try:
+                    with open(os.path.join(ROOT, "profiles", src)) as f:
+                        traffic = json.load(f).get(name, {}).get("traffic_bytes_per_step")
+                except (OSError, ValueError):
+                    traffic = None
+                if traffic is not None:
+                    traffic_note = "profiles/%s: (2 x FETCH_SIZE + WRITE_SIZE) x 1024, separate --pmc passes over this command" % src
+                    break
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kernel,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note, "kernel": kernel,
                 "kernel_ms": round(kernel_ms, 4), "alg_bytes_per_sample": alg_bps}
     if kernel == "scan2400_kernel" and not dc and nrec == 1:
         # what binds the scan kernel is VALU issue, not HBM: instruction counts per strip from the committed
         # PMC pass (profiles/README.md) priced at 4 cycles per wave64 instruction and 1024 SIMDs at 2.4 GHz
-        try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_scan_stages.json")) as f:
-                pm = json.load(f)[fmt]["per_strip"]["through_stage_D"]
-            floor_ms = pm["INSTS_VALU"] * 4 * (nsamples / 2048 / 1024) / 2.4e9 * 1e3
-            roofline["valu_issue"] = {"insts_per_2048_positions": pm["INSTS_VALU"], "floor_ms": round(floor_ms, 4),
+        for src in PMC_STAGE_FILES:
+            try:
+                with open(os.path.join(ROOT, "profiles", src)) as f:
+                    pm = json.load(f)[fmt]["per_strip"]["through_stage_D"]
+            except (OSError, KeyError, ValueError):
+                continue
+            # measured issue cost (profiles/r03_ubench_valu_rate*.txt): 4.2-4.5 cycles per wave64 instruction and SIMD at
+            # 4-8 waves per SIMD for the kinds this kernel is made of (VOP3, compares, selects, DPP, dot, 24-bit
+            # multiplies); only plain 32-bit add / and / or / xor / shift-right / move issue in 2.4-2.9
+            floor_ms = pm["INSTS_VALU"] * VALU_ISSUE_CYCLES * (nsamples / 2048 / 1024) / 2.4e9 * 1e3
+            roofline["valu_issue"] = {"insts_per_2048_positions": pm["INSTS_VALU"], "cycles_per_inst": VALU_ISSUE_CYCLES,
+                                      "floor_ms": round(floor_ms, 4),
                                       "frac_of_kernel_ms": round(floor_ms / kernel_ms, 3) if kernel_ms > 0 else None,
-                                      "source": "profiles/r02_pmc_scan_stages.json"}
-        except (OSError, KeyError):
-            pass
+                                      "source": "profiles/" + src}
+            break
     if kernel in ("scan2400_kernel", "scan2000_kernel") and not dc and nrec == 1 and not sharded:
         # A message-heavy shard is scanned in ranges of blocks whose launches share the GPU with the ordered pass and the
         # read-back of the range before (kernel_ms above: their sum, as timed inside the step).  The same kernel alone:
@@ -288,7 +383,8 @@ def run_workload(name, args, world, rank, local, dev, want_cpu):
         except Exception as ex:                    # a report, never a reason to lose the bench line
             roofline["kernel_ms_alone"] = repr(ex)
     if k2:
-        roofline["second_kernel"] = {"kernel": "scan2400_kernel" if dc else "d8_trig_kernel", "kernel_ms": round(k2 / args.steps / nrec, 4)}
+        roofline["second_kernel"] = {"kernel": "scan2400_kernel" if dc else "d8_trig_kernel", "kernel_ms": round(k2 / args.steps / nrec, 4),
+                                     "note": "included in kernel_ms" if rate == 8000000 else "runs behind the chain, not in kernel_ms"}
     if dc:
         roofline["dc_chain"] = last_eng.dc_info()
 
@@ -326,33 +422,9 @@ def run_workload(name, args, world, rank, local, dev, want_cpu):
                                            ("valid_preamble", "demodulated", "CRC_good", "CRC_bad", "CRC_single_bit_fix")))
             cpu["valid_preamble"] = int(ost["valid_preamble"])
 
-    if cpu is not None and args.cpu_all_cores:
+    if cpu is not None and args.cpu_all_cores and not dc and rate != 8000000:
         try:
-            # the same sample once per host core, as independent streams (the reference has no intra-stream parallelism:
-            # one reader thread + one demodulator thread, ref: src/dump1090.c:1298,1367): aggregate CPU throughput.
-            # Fresh interpreter processes (no torch, no HIP): nothing of this process's GPU state is forked.
-            import subprocess
-            import tempfile
-            cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
-            small = host[: max(8, nblk // 8) * 262144 // host.itemsize]
-            with tempfile.TemporaryDirectory() as td:
-                path = os.path.join(td, "sample.npy")
-                np.save(path, small)
-                argv = [sys.executable, "-c", _CPU_WORKER, path, str(rate), fmt, str(ekw.get("fix_bits", 1)), str(int(power)),
-                        str(int(dc)), str(int(bool(ekw.get("mode_ac"))))]
-                procs = [subprocess.Popen(argv, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for _ in range(cores)]
-                for pr in procs:
-                    assert pr.stdout.readline().strip() == "ready"
-                t0 = time.perf_counter()
-                for pr in procs:
-                    pr.stdin.write("go\n"); pr.stdin.flush()
-                for pr in procs:
-                    assert pr.stdout.readline().startswith("done")
-                adt = time.perf_counter() - t0
-                for pr in procs:
-                    pr.stdin.close(); pr.wait()
-            cpu["all_cores"] = {"value": round(cores * (small.nbytes // bps) / adt / 1e6, 2), "unit": "Msamples/s", "cores": cores,
-                                "sample": "%d independent copies of the first %d MiB, one oracle process per core" % (cores, small.nbytes >> 20)}
+            cpu["all_cores"] = cpu_all_cores(host, rate, fmt, bps, ekw.get("fix_bits", 1), power, bool(ekw.get("mode_ac")), len(cpu_msgs))
         except Exception as ex:                    # the baseline is a report, never a reason to lose the bench line
             cpu["all_cores"] = {"error": repr(ex)}
 
@@ -386,7 +458,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-cpu-all-cores", dest="cpu_all_cores", action="store_false",
                     help="skip the all-host-cores leg of the CPU baseline (independent streams, one per core)")
-    ap.add_argument("--no-also", action="store_true", help="skip the companion sc16 line of the default workload")
+    ap.add_argument("--no-also", action="store_true", help="skip the companion lines of the default workload")
     ap.add_argument("--traffic", type=float, default=None, help="HBM bytes per launch of the roofline kernel from PMC counters")
     args = ap.parse_args()
 
@@ -414,9 +486,11 @@ def main():
         # Companion lines: the same kernel instance on an input it does decode (uc8_2400_lut), the uc8 path that
         # decodes real IQ and that the reference's shipped dump1090.cfg selects (uc8_2400_dc), and the same signal as sc16.
         also = {}
-        for wl in ("uc8_2400_lut", "uc8_2400_dc", "sc16_2400"):
+        # ... and BASELINE.json's other configs: configs[2] (sc16_2000), configs[3] (sc16_8000: one 4 GiB shard of the
+        # capture) and configs[4] (sc16_2400ac: the batch of 64 recordings), each with its bounded CPU prefix and parity.
+        for wl in ("uc8_2400_lut", "uc8_2400_dc", "sc16_2400", "sc16_2000", "sc16_8000", "sc16_2400ac"):
             args2 = argparse.Namespace(**vars(args))
-            args2.cpu_seconds = 4.0
+            args2.cpu_seconds = 4.0 if wl in ("uc8_2400_lut", "uc8_2400_dc", "sc16_2400") else 3.0
             args2.cpu_all_cores = False
             args2.steps, args2.warmup = min(args.steps, 5), min(args.warmup, 2)
             torch.cuda.empty_cache()
