@@ -16,7 +16,12 @@ enum Conv : int {
   kConvMagU16 = 6,    // not a converter: the input already is the uint16 magnitude buffer of a mag_buf
   // scan2400_kernel only: kConvUc8Lut with the LDS tile holding, per sample, the rank of its magnitude among the byte
   // table's values (one byte instead of two: half the LDS, more waves per SIMD); magnitudes are looked up where needed
-  kConvUc8LutR8 = 7
+  kConvUc8LutR8 = 7,
+  // scan2400_kernel only: kConvUc8Lut with the LDS tile holding the RAW input bytes, brought in by LDS-DMA
+  // (global_load_lds_dwordx4: no register staging, every byte of a workgroup's span in flight at once).  Stage B looks
+  // the ranks of its own 33 bytes up (byte -> rank, what only orders samples), later stages the magnitudes (byte ->
+  // table value) of the few positions they look at.
+  kConvUc8LutRaw = 8
 };
 
 // ---- scan kernel geometry (2.4 MS/s) -------------------------------------------------
@@ -126,10 +131,13 @@ struct ScanParams {
   uint32_t        strip_begin, strip_end;
   // kConvUc8LutR8: rank256[byte] = rank of lut256[byte] among the table's distinct values, rankmag[rank] = that value
   // (0xFFFF behind the last rank); *inexact is set when a halo magnitude is none of the table's values
+  // kConvUc8LutRaw: rank256 and lut256; the tile holds input bytes, a halo magnitude is mapped back to a byte with that value
   const uint8_t  *rank256;
   const uint16_t *rankmag;
   uint32_t       *inexact;
 };
+constexpr uint32_t kOv2400 = 326;                               // (8 + 112 + 16) us at 2.4 MS/s (ref: src/dump1090.c:734)
+constexpr int kRawShift2400 = int ((16 - kOv2400 % 16) % 16);   // sample of V[16 k] sits this many bytes into a 16-byte chunk of input
 
 }  // namespace modes
 

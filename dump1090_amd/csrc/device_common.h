@@ -500,6 +500,67 @@ __device__ __forceinline__ void stage_tile_rank8 (uint8_t *tile, const uint8_t *
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// kConvUc8LutRaw: the tile holds the input bytes themselves.  tile[x] = the byte the as-written converter reads for
+// sample a0 + x (a0 a multiple of 16, the tile 16-byte aligned): one global_load_lds_dwordx4 moves 1 KiB (64 lanes x 16
+// bytes) from per-lane source addresses to consecutive LDS bytes without touching a register.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void glds16 (const uint8_t *src, uint8_t *lds_wave_base)
+{
+  __builtin_amdgcn_global_load_lds ((const __attribute__ ((address_space (1))) void *) src,
+                                    (__attribute__ ((address_space (3))) void *) lds_wave_base, 16, 0, 0);
+}
+
+// byte the as-written converter reads for sample n (ref: src/convert.c:19,29): byte n % B of block n / B
+__device__ __forceinline__ const uint8_t *lut_byte_addr (const ScanParams &p, long long n)
+{
+  const uint64_t in_blk = uint64_t (n) & uint64_t (p.block_samples - 1);     // block_samples is a power of two
+  return p.iq + 2 * (uint64_t (n) - in_blk) + in_blk;
+}
+
+// a byte whose table value is the magnitude m (the halo in front of a shard): exact only if m is one of the table's values
+__device__ __forceinline__ uint32_t byte_of_mag (const uint16_t *lut, uint32_t m, const ScanParams &p)
+{
+  for (int b = 0; b < 256; b++) if (lut[b] == m) return uint32_t (b);
+  if (p.inexact) atomicOr (p.inexact, 1u);
+  return 0u;
+}
+
+__device__ __forceinline__ uint32_t raw_byte_of_sample (const uint16_t *lut, const ScanParams &p, long long n, long long N)
+{
+  if (n < 0) {
+    const uint32_t m = (p.halo && n + (long long) p.ov >= 0) ? p.halo[n + (long long) p.ov] : 0u;
+    return m ? byte_of_mag (lut, m, p) : 0u;                       // the table maps byte 0 to magnitude 0
+  }
+  if (n >= N) return 0u;
+  return *lut_byte_addr (p, n);
+}
+
+// kBytes (a multiple of 16) bytes of tile from sample a0 on, by the kWaves waves of a workgroup
+template <int kBytes, int kWaves>
+__device__ __forceinline__ void stage_tile_raw (uint8_t *tile, const uint16_t *lut, const ScanParams &p, long long a0, int wv, int lane, int tid)
+{
+  const long long N = (long long) p.nsamples;
+  constexpr int kPieces = kBytes / 1024, kTailLanes = (kBytes % 1024) / 16;
+  if (a0 >= 0 && a0 + kBytes <= N) {
+#pragma unroll
+    for (int pc = 0; pc < (kPieces + kWaves - 1) / kWaves; pc++) {
+      const int piece = pc * kWaves + wv;                          // wave-uniform
+      if (piece < kPieces) glds16 (lut_byte_addr (p, a0 + 1024ll * piece + 16 * lane), tile + 1024 * piece);
+    }
+    if (kTailLanes && wv == kPieces % kWaves && lane < kTailLanes)
+      glds16 (lut_byte_addr (p, a0 + 1024ll * kPieces + 16 * lane), tile + 1024 * kPieces);
+    return;
+  }
+  // first / last workgroups of the shard: per-sample bounds
+  for (int c = tid * 4; c < kBytes; c += 64 * kWaves * 4) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) w |= raw_byte_of_sample (lut, p, a0 + c + k, N) << (8 * k);
+    *reinterpret_cast<uint32_t *> (tile + c) = w;
+  }
+}
+
 // Reads of the magnitude tile: `mag` for arithmetic, `ord` where only the order of two samples matters.
 template <bool R8> struct TileRef;
 template <> struct TileRef<false> {

@@ -594,7 +594,10 @@ ScanParams scan_variant (modes_engine *e, const ScanParams &sp)
   const bool off = getenv ("MODES_NO_RANK_TILE") != nullptr;          // tests: compare against the magnitude tile
   if (e->mode == 2400 && !off && !e->no_rank_tile && !e->cfg.host_replay && !e->cfg.phase_enhance && e->rb.p &&
       (sp.conv == kConvUc8Lut || sp.conv == kConvUc8LutPower) && sp.block_strips) {
-    q.conv = kConvUc8LutR8;
+    // the input bytes by LDS-DMA where whole 16-byte chunks line up with the scan positions (they do for hipMalloc'ed
+    // recordings); MODES_RANK_TILE_GATHER=1 keeps the register-staged rank tile (tests, comparisons)
+    const bool raw = !getenv ("MODES_RANK_TILE_GATHER") && sp.ov == kOv2400 && !(reinterpret_cast<uintptr_t> (sp.iq) & 15) && !(sp.block_samples & 15);
+    q.conv = raw ? kConvUc8LutRaw : kConvUc8LutR8;
     q.rank256 = e->tabs.rank256; q.rankmag = e->tabs.rankmag;
     q.inexact = e->rb.p + kRbInexactWord;
   }

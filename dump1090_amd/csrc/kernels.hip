@@ -27,14 +27,14 @@ namespace modes {
 // time) as to the instruction count: the byte-table instance comes out 3.6 % faster, the sc16 one 6 % slower.  So the
 // byte-table converters run with PAIR = 2, the others with single strips.  kConvUc8LutR8 -- the byte-table instance whose
 // tile holds ranks, one byte per sample (device_common.h) -- has the pair AND the 6 waves: a further 8 % faster.
-template <int CONV> struct ScanPair { static constexpr int n = (CONV == kConvUc8Lut || CONV == kConvUc8LutPower || CONV == kConvUc8LutR8) ? 2 : 1; };
+template <int CONV> struct ScanPair { static constexpr int n = (CONV == kConvUc8Lut || CONV == kConvUc8LutPower || CONV == kConvUc8LutR8 || CONV == kConvUc8LutRaw) ? 2 : 1; };
 // Waves per SIMD the register allocation aims for.  With the wave number read as a scalar (below) the integer sc16
 // instance and the rank tile fit 72 registers, and their 21 / 22.6 KB of LDS per workgroup leave room for seven
 // workgroups per CU: 3 % faster than six.  The float converters spill at six already and stay there.
 template <int CONV, bool PE> struct ScanWaves {
   static constexpr int n = (CONV == kConvSc16Generic || CONV == kConvSc16Q11Generic) ? SCANF_WAVES :
                            (!PE && (CONV == kConvUc8Lut || CONV == kConvUc8LutPower)) ? 4 :       // two strips of magnitudes per wave: 39 KB of LDS per workgroup
-                           (!PE && (CONV == kConvUc8LutR8 || CONV == kConvSc16Int || CONV == kConvMagU16)) ? 7 : 6;
+                           (!PE && (CONV == kConvUc8LutR8 || CONV == kConvUc8LutRaw || CONV == kConvSc16Int || CONV == kConvMagU16)) ? 7 : 6;
 };
 constexpr int kWavesPerBlock = 4;
 constexpr int kQ1Seg = 256;
@@ -96,14 +96,17 @@ template <int CONV, bool PE>
 __global__ __launch_bounds__ (64 * kWavesPerBlock) __attribute__ ((amdgpu_waves_per_eu (ScanWaves<CONV, PE>::n, ScanWaves<CONV, PE>::n)))
 void scan2400_kernel (const ScanParams p)
 {
-  constexpr bool kR8 = CONV == kConvUc8LutR8;       // the tile holds ranks (one byte per sample), not magnitudes
+  constexpr bool kRaw = CONV == kConvUc8LutRaw;     // the tile holds the input bytes (LDS-DMA), ranks and magnitudes are looked up
+  constexpr bool kR8 = CONV == kConvUc8LutR8 || kRaw;   // the tile holds one byte per sample (ranks, or input bytes), not magnitudes
   constexpr bool kLut = CONV == kConvUc8Lut || CONV == kConvUc8LutPower || kR8;
   constexpr int kPair = PE ? 1 : ScanPair<CONV>::n;
   constexpr int kSpan = kPair * kStrip;                           // positions one wave scans
   constexpr int kGroupSpan = kWavesPerBlock * kSpan;              // positions one workgroup scans
   constexpr int kStageHalf = kGroupSpan / 2;                      // the tile is staged in two goes (registers)
-  constexpr int kTileN = kStageHalf + 8 * TileChunks<kStageHalf + kLook2400>::n;
-  constexpr int kLead = kR8 ? kTileLead8 : kTileLead;
+  // raw tile: s_tile[x] = input byte of sample a0 + x, a0 = (sample of V[G0]) - kRawShift2400, in whole 16-byte chunks
+  constexpr int kRawBytes = (kRawShift2400 + kGroupSpan + kLook2400 + 15) / 16 * 16;
+  constexpr int kTileN = kRaw ? kRawBytes : kStageHalf + 8 * TileChunks<kStageHalf + kLook2400>::n;
+  constexpr int kLead = kRaw ? 0 : kR8 ? kTileLead8 : kTileLead;
   static_assert (kSpan <= 4096, "queue entries keep a position of the span in 12 bits");
   static_assert (!(kR8 && PE), "the rank tile is built for the plain scan only");
   using TileT = typename std::conditional<kR8, uint8_t, uint16_t>::type;
@@ -115,9 +118,9 @@ void scan2400_kernel (const ScanParams p)
   const int wv = __builtin_amdgcn_readfirstlane (int (threadIdx.x >> 6));    // wave-uniform: what derives from it is scalar arithmetic
   WaveLds<PE, kPair> &w = lds[wv];
   if (kLut) {
-    s_lut[threadIdx.x] = kR8 ? p.rankmag[threadIdx.x] : p.lut256[threadIdx.x];
+    s_lut[threadIdx.x] = (kR8 && !kRaw) ? p.rankmag[threadIdx.x] : p.lut256[threadIdx.x];
     if (kR8) s_rank[threadIdx.x] = p.rank256[threadIdx.x];
-    __syncthreads ();
+    if (!kRaw) __syncthreads ();                  // (the raw tile's staging reads the tables only on its slow path, behind a barrier of its own)
   }
   const uint32_t strip = p.strip_begin + (blockIdx.x * kWavesPerBlock + wv) * kPair;   // first strip of this wave's span
   const uint32_t strip_end = p.strip_end ? p.strip_end : p.nstrips;
@@ -131,7 +134,12 @@ void scan2400_kernel (const ScanParams p)
   // ---- stage A: magnitudes V[G0 .. G0 + 4 spans + kLook2400) into LDS, staged by the whole workgroup in two goes ----
   const long long G0 = (long long) p.strip_begin * kStrip + (long long) blockIdx.x * kGroupSpan;
   const long long s0 = G0 - (long long) (CONV == kConvMagU16 ? 0u : p.ov);   // sample index of V[G0] (may be < 0)
-  if constexpr (kR8) {
+  if constexpr (kRaw) {
+    const long long a0 = s0 - kRawShift2400;        // G0 and the launch's first strip are multiples of 16, ov = kOv2400
+    if (!(a0 >= 0 && a0 + kRawBytes <= (long long) p.nsamples)) __syncthreads ();     // workgroup-uniform: the slow path reads s_lut
+    stage_tile_raw<kRawBytes, kWavesPerBlock> (s_tile, s_lut, p, a0, wv, lane, int (threadIdx.x));
+    asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");       // the DMA writes land before the barrier lets anyone read
+  } else if constexpr (kR8) {
     stage_tile_rank8<kStageHalf, 64 * kWavesPerBlock> (s_tile + kLead, s_rank, s_lut, p, s0, int (threadIdx.x));
     stage_tile_rank8<kStageHalf + kLook2400, 64 * kWavesPerBlock> (s_tile + kLead + kStageHalf, s_rank, s_lut, p, s0 + kStageHalf, int (threadIdx.x));
   } else {
@@ -141,7 +149,9 @@ void scan2400_kernel (const ScanParams p)
   __syncthreads ();
   if (strip >= strip_end) return;
   const long long P0 = (long long) strip * kStrip;
-  const TileRef<kR8> V { s_tile + kLead + wv * kSpan, s_lut };
+  const TileRef<kR8> V { s_tile + (kRaw ? kRawShift2400 : kLead) + wv * kSpan, s_lut };
+  // order key of one sample: the magnitude, its rank, or (raw tile) the rank of the byte
+  auto ordv = [&] (const TileRef<kR8> &T, int i) -> uint32_t { if constexpr (kRaw) return s_rank[T.p[i]]; else return T.ord (i); };
 
   if (p.debug_stop == 1) { if (lane == 0) p.counts[strip] = V.ord (lane); return; }
 
@@ -152,9 +162,27 @@ void scan2400_kernel (const ScanParams p)
     const TileRef<kR8> Vh = V.at (h * kStrip);
     uint32_t LT = 0, GT = 0;
     if constexpr (kR8) {
-      const uint4 *vw = reinterpret_cast<const uint4 *> (Vh.p + 32 * lane);
-      const uint4 x0 = vw[0], x1 = vw[1];
-      const uint32_t wd[9] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, Vh.ord (32 * lane + 32) };
+      uint32_t wd[9];
+      if constexpr (kRaw) {
+        // the lane's 33 input bytes sit kRawShift2400 bytes into three aligned 16-byte reads; their ranks are gathered
+        // from the 256-byte table and packed four to a word
+        const uint4 *vw = reinterpret_cast<const uint4 *> (s_tile + wv * kSpan + h * kStrip + 32 * lane);
+        const uint4 y0 = vw[0], y1 = vw[1], y2 = vw[2];
+        const uint32_t W[12] = { y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w, y2.x, y2.y, y2.z, y2.w };
+        constexpr int kW = kRawShift2400 / 4, kB = kRawShift2400 % 4;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+          const uint32_t b4 = kB ? __builtin_amdgcn_alignbyte (W[k + kW + 1], W[k + kW], kB) : W[k + kW];
+          if (k < 8) wd[k] = uint32_t (s_rank[b4 & 0xFF]) | (uint32_t (s_rank[(b4 >> 8) & 0xFF]) << 8) |
+                             (uint32_t (s_rank[(b4 >> 16) & 0xFF]) << 16) | (uint32_t (s_rank[b4 >> 24]) << 24);
+          else       wd[k] = s_rank[b4 & 0xFF];
+        }
+      } else {
+        const uint4 *vw = reinterpret_cast<const uint4 *> (Vh.p + 32 * lane);
+        const uint4 x0 = vw[0], x1 = vw[1];
+        wd[0] = x0.x; wd[1] = x0.y; wd[2] = x0.z; wd[3] = x0.w; wd[4] = x1.x; wd[5] = x1.y; wd[6] = x1.z; wd[7] = x1.w;
+        wd[8] = Vh.ord (32 * lane + 32);
+      }
       // Four neighbour pairs are compared per word: with H = 0x80 and L = 0x7F in every byte, (x | H) - (y & L) never
       // borrows between bytes and keeps bit 7 where the low seven bits of x are >= those of y; the top bits decide
       // otherwise.  v_dot4 with (1, 2, 4, 8) / (16, 32, 64, 128) then packs the four verdicts of a word next to those
@@ -194,7 +222,7 @@ void scan2400_kernel (const ScanParams p)
     }
     uint32_t LTn = dpp_mov<0x130, 0xF, true> (LT), GTn = dpp_mov<0x130, 0xF, true> (GT);   // wave_shl:1 = lane + 1's word
     {   // the word behind the strip, for lane 63
-      const uint32_t a = Vh.ord (kStrip + (lane & 15)), b = Vh.ord (kStrip + (lane & 15) + 1);
+      const uint32_t a = ordv (Vh, kStrip + (lane & 15)), b = ordv (Vh, kStrip + (lane & 15) + 1);
       const uint32_t l = uint32_t (__ballot (a < b)) & 0xFFFFu, g = uint32_t (__ballot (a > b)) & 0xFFFFu;
       if (lane == 63) { LTn = l; GTn = g; }
     }
@@ -1392,12 +1420,18 @@ hipError_t launch_scan2400 (const ScanParams &p, hipStream_t stream)
     case kConvSc16Generic:    SCAN (kConvSc16Generic); break;
     case kConvSc16Q11Generic: SCAN (kConvSc16Q11Generic); break;
     case kConvMagU16:         SCAN (kConvMagU16); break;
-    case kConvUc8LutR8: {
+    case kConvUc8LutR8: case kConvUc8LutRaw: {
       if (p.phase_enhance || !p.rank256 || !p.rankmag) return hipErrorInvalidValue;
       const uint32_t pair = uint32_t (ScanPair<kConvUc8LutR8>::n);
       const uint32_t nspans = ((p.strip_end ? p.strip_end : p.nstrips) - p.strip_begin + pair - 1) / pair;
       const dim3 grid ((nspans + kWavesPerBlock - 1) / kWavesPerBlock);
-      hipLaunchKernelGGL ((scan2400_kernel<kConvUc8LutR8, false>), grid, block, 0, stream, p);
+      if (p.conv == kConvUc8LutRaw) {
+        // whole 16-byte chunks of input behind every 16th scan position: ov as demod_2400's, the input 16-byte aligned
+        if (p.ov != kOv2400 || (reinterpret_cast<uintptr_t> (p.iq) & 15) || (p.block_samples & 15) || ((p.strip_begin * uint64_t (kStrip)) & 15))
+          return hipErrorInvalidValue;
+        hipLaunchKernelGGL ((scan2400_kernel<kConvUc8LutRaw, false>), grid, block, 0, stream, p);
+      } else
+        hipLaunchKernelGGL ((scan2400_kernel<kConvUc8LutR8, false>), grid, block, 0, stream, p);
       break;
     }
     default: return hipErrorInvalidValue;
