@@ -173,9 +173,11 @@ void scan2400_kernel (const ScanParams p)
 #pragma unroll
         for (int k = 0; k < 9; k++) {
           const uint32_t b4 = kB ? __builtin_amdgcn_alignbyte (W[k + kW + 1], W[k + kW], kB) : W[k + kW];
-          if (k < 8) wd[k] = uint32_t (s_rank[b4 & 0xFF]) | (uint32_t (s_rank[(b4 >> 8) & 0xFF]) << 8) |
-                             (uint32_t (s_rank[(b4 >> 16) & 0xFF]) << 16) | (uint32_t (s_rank[b4 >> 24]) << 24);
-          else       wd[k] = s_rank[b4 & 0xFF];
+          if (k < 8) {
+            const uint32_t r0 = s_rank[b4 & 0xFF], r1 = s_rank[(b4 >> 8) & 0xFF], r2 = s_rank[(b4 >> 16) & 0xFF], r3 = s_rank[b4 >> 24];
+            const uint32_t lo = __builtin_amdgcn_perm (r1, r0, 0x0c0c0400u), hi = __builtin_amdgcn_perm (r3, r2, 0x0c0c0400u);
+            wd[k] = __builtin_amdgcn_perm (hi, lo, 0x05040100u);
+          } else wd[k] = s_rank[b4 & 0xFF];
         }
       } else {
         const uint4 *vw = reinterpret_cast<const uint4 *> (Vh.p + 32 * lane);
@@ -288,8 +290,8 @@ void scan2400_kernel (const ScanParams p)
       while (mm) {
         const int b = __builtin_ctz (mm);
         mm &= mm - 1;
-        const uint32_t pat = ((c0[h] >> b) & 1u) | (((c1[h] >> b) & 1u) << 1) | (((c2[h] >> b) & 1u) << 2);
-        if (uint32_t (slot) < uint32_t (kQ1Seg)) w.q1[slot] = uint16_t ((h * kStrip + 32 * lane + b) | (pat << 12));
+        // (the layout index stays in the code planes of the lane that owns the position: stage C1 fetches it from there)
+        if (uint32_t (slot) < uint32_t (kQ1Seg)) w.q1[slot] = uint16_t (h * kStrip + 32 * lane + b);
         slot++;
       }
     }
@@ -302,11 +304,23 @@ void scan2400_kernel (const ScanParams p)
     for (int base = 0; base < nseg; base += 64) {
       const int qi = base + lane;
       bool amp = false;
-      int off = 0;
+      int off = qi < nseg ? int (w.q1[qi]) : 0;
+      // layout index 0..4 of the candidate: bit (off & 31) of the three code planes of lane (off >> 5) & 63
+      int pat;
+      {
+        const int src = (off >> 3) & 0xFC;                          // byte address of the owning lane for ds_bpermute
+        uint32_t k0 = uint32_t (__builtin_amdgcn_ds_bpermute (src, int (c0[0]))), k1 = uint32_t (__builtin_amdgcn_ds_bpermute (src, int (c1[0]))),
+                 k2 = uint32_t (__builtin_amdgcn_ds_bpermute (src, int (c2[0])));
+        if (kPair > 1) {
+          const uint32_t j0 = uint32_t (__builtin_amdgcn_ds_bpermute (src, int (c0[kPair - 1]))), j1 = uint32_t (__builtin_amdgcn_ds_bpermute (src, int (c1[kPair - 1]))),
+                         j2 = uint32_t (__builtin_amdgcn_ds_bpermute (src, int (c2[kPair - 1])));
+          const bool hi = off >= kStrip;
+          k0 = hi ? j0 : k0; k1 = hi ? j1 : k1; k2 = hi ? j2 : k2;
+        }
+        const int b = off & 31;
+        pat = int (((k0 >> b) & 1u) | (((k1 >> b) & 1u) << 1) | (((k2 >> b) & 1u) << 2));
+      }
       if (qi < nseg) {
-        const uint32_t qe = w.q1[qi];
-        off = qe & 0xFFF;
-        const int pat = qe >> 12;
         const TileRef<kR8> pp = V.at (off);
         int s[19];
 #pragma unroll
