@@ -209,7 +209,10 @@ struct D8Params {
 // ---- float converters with the DC block on, whole recording (kernels_dc.hip) ----------------
 // One chain of the filter per chunk: it starts at sample `start` (<= the chunk's first sample, may reach back
 // into the lead-in in front of the shard) from the bracket [lo, hi] per channel; lo == hi when the state is known.
-constexpr int kDcBatch = 4096;         // samples a workgroup stages per round: sixteen per thread
+#ifndef DC_BATCH
+#define DC_BATCH 4096
+#endif
+constexpr int kDcBatch = DC_BATCH;     // samples a workgroup stages per round: sixteen per thread
 constexpr int kDcSeg = 65536;          // samples per segment of the real-arithmetic estimate (dc_linear_kernel)
 struct DcChunk {
   long long start;                     // first sample the chain steps (<= the chunk's first sample)

@@ -513,7 +513,8 @@ int prepare_dc (modes_engine *e, const void *d_iq, size_t nbytes, const uint16_t
     std::sort (order.begin (), order.end (), [&] (uint64_t a, uint64_t b) { return tk[16 * a] > tk[16 * b]; });
     for (uint64_t i = 0; i < K && i < 6; i++) {
       const uint64_t c = order[i];
-      fprintf (stderr, "  slowest: chunk %4llu: %9llu ticks, %7llu rounds, %6llu plain, chain %llu, barriers %llu\n", (unsigned long long) c, tk[16 * c], tk[16 * c + 1], tk[16 * c + 2], tk[16 * c + 3], tk[16 * c + 4]);
+      fprintf (stderr, "  slowest: chunk %4llu: %9llu ticks, %7llu rounds, %6llu plain, chain %llu, barriers %llu; rounds per wave %llu %llu %llu %llu; start %lld closed_at %lld (chunk begins %llu)\n", (unsigned long long) c, tk[16 * c], tk[16 * c + 1], tk[16 * c + 2], tk[16 * c + 3], tk[16 * c + 4],
+               tk[16 * c + 5], tk[16 * c + 7], tk[16 * c + 9], tk[16 * c + 11], desc[c].start, closed[c], (unsigned long long) (c * L));
     }
     uint64_t open_chunks = 0;
     for (uint64_t c = 0; c < K; c++) open_chunks += unm[c];

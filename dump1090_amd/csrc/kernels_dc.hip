@@ -82,9 +82,15 @@ __device__ __forceinline__ float wave_incl_scan_f (float v)
 __device__ __forceinline__ int dcp (int i) { return i; }
 constexpr int kDcBatchLds = kDcBatch;
 
-constexpr int kDcPer = 16;                      // consecutive samples per lane in one round
+#ifndef DC_PER
+#define DC_PER 16
+#endif
+#ifndef DC_ITERS
+#define DC_ITERS 16
+#endif
+constexpr int kDcPer = DC_PER;                  // consecutive samples per lane in one round
 constexpr int kDcRound = 64 * kDcPer;           // samples per round
-constexpr int kDcIters = 4;                     // refinements of the lanes' start values per round
+constexpr int kDcIters = DC_ITERS;              // refinements of the lanes' start values per round
 
 __device__ __forceinline__ float bcast_lane (float x, int l)
 {
@@ -103,20 +109,28 @@ __device__ __forceinline__ float bcast_lane (float x, int l)
 // exact by induction from z0, whatever the guesses were.
 // tk[q] = t of sample kDcPer * lane + q; nl = lanes that hold samples.  On return zt[q] = z1 behind that sample as
 // stepped from the lane's start; the result is the number of leading lanes whose values are proven (>= 1).
-__device__ __forceinline__ int dc_round (const float *tk, float z0, float B, int lane, int nl, float *zt)
+__device__ __forceinline__ int dc_round (const float *tk, float z0, float B, int lane, int nl, float *zt, float &leak_adj, uint32_t &n_pass)
 {
   // first guess: the filter in real arithmetic, z' = z + t - z (1 - B), with z ~ z0 over the round
-  float start;
+  float start, guess_end;
   {
     float ts = 0.0f;
 #pragma unroll
     for (int q = 0; q < kDcPer; q++) ts += tk[q];
-    const float leak = z0 - z0 * B;
+    // What z1 loses per step: z - RN (z * B) at z0, an integer number of ulps -- where the filter has settled (an input
+    // with a DC component and little else) z1 dithers across the point where that integer changes, and the loss per
+    // step is in between: `leak_adj` carries the average the last complete round really lost beyond it.
+#ifndef DC_LEAK_ADJ
+    leak_adj = 0.0f;                      // (measured: the passes a round needs do not hang on the first guess; 4 % slower with it)
+#endif
+    const float leak = (z0 - z0 * B) + leak_adj;
     const float inc = ts - float (kDcPer) * leak;
     const float incl = wave_incl_scan_f (inc);
     start = z0 + (incl - inc);
+    guess_end = bcast_lane (z0 + incl, nl - 1);
   }
   int good = 1;
+#ifdef DC_RESTART
 #pragma unroll 1
   for (int it = 0; it < kDcIters; it++) {
     float z = start;
@@ -131,12 +145,40 @@ __device__ __forceinline__ int dc_round (const float *tk, float z0, float B, int
     const float incl = wave_incl_scan_f (inc);
     start = __fadd_rn (z0, __fsub_rn (incl, inc));
   }
+#else
+  // Lanes below `good` are proven and keep their starts; the others take theirs from the end of the last proven lane
+  // plus the increments the lanes between them made in this pass -- sums that start at the proven front, so they stay
+  // small and exact where the chain sits still, and the pass after a miss starts from this pass's knowledge instead of
+  // the first guess a new round would make.
+#pragma unroll 1
+  for (int it = 0; it < kDcIters; it++) {
+    float z = start;
+#ifdef DC_COUNT_PASSES
+    n_pass++;
+#endif
+#pragma unroll
+    for (int q = 0; q < kDcPer; q++) { z = __fadd_rn (tk[q], __fmul_rn (z, B)); zt[q] = z; }
+    float below = __uint_as_float (dpp_mov<0x138, 0xF, true> (__float_as_uint (z)));     // wave_shr:1: the lane below
+    if (lane == 0) below = z0;
+    const u64 bad = __ballot (__float_as_uint (below) != __float_as_uint (start) && lane < nl);
+    good = bad ? __builtin_ctzll (bad) : nl;      // (a proven lane's start never changes below, so it is never the first miss)
+    if (good == nl || it == kDcIters - 1) break;
+    const float zg = bcast_lane (z, good - 1);    // the proven front: z1 in front of lane `good`
+    const float inc = lane >= good ? __fsub_rn (z, start) : 0.0f;
+    const float incl = wave_incl_scan_f (inc);
+    if (lane >= good) start = __fadd_rn (zg, __fsub_rn (incl, inc));
+  }
+#endif
+  if (good == nl) {      // what the first guess missed, per step, goes into the next round's guess
+    const float true_end = bcast_lane (zt[kDcPer - 1], nl - 1);
+    leak_adj += (guess_end - true_end) / float (kDcPer * nl);
+  }
   return good;
 }
 
 // One chain over t[0 .. cnt): returns z1 behind the last sample, zo[i] = z1 behind sample i.  z0 is uniform.
 // t and zo are 16-byte aligned and hold kDcBatch entries (entries at and beyond cnt are never used in a result).
-__device__ __forceinline__ float dc_chain_batch (const float *t, float *zo, bool store, int cnt, float z0, float B, int lane, uint32_t &n_guess, uint32_t &n_plain)
+__device__ __forceinline__ float dc_chain_batch (const float *t, float *zo, bool store, int cnt, float z0, float B, int lane, uint32_t &n_guess, uint32_t &n_plain, float &leak_adj)
 {
   int base = 0;
   while (base < cnt) {
@@ -160,7 +202,7 @@ __device__ __forceinline__ float dc_chain_batch (const float *t, float *zo, bool
 #pragma unroll
       for (int q = 0; q < kDcPer; q++) tk[q] = 0.0f;
     }
-    const int good = dc_round (tk, z0, B, lane, nl, zt);         // >= 1: lane 0 starts from z0 itself
+    const int good = dc_round (tk, z0, B, lane, nl, zt, leak_adj, n_plain);         // >= 1: lane 0 starts from z0 itself
     if (store && lane < good) {
       float4 *dst = reinterpret_cast<float4 *> (zo + dcp (base + kDcPer * lane));
 #pragma unroll
@@ -172,15 +214,56 @@ __device__ __forceinline__ float dc_chain_batch (const float *t, float *zo, bool
   return z0;
 }
 
+// Magnitudes of samples [b + off, b + off + 2048) of a batch whose z1 values lie in zI / zQ (ref: src/convert.c:139-147):
+// one wave, 32 samples per lane in eight goes of four.  The raw samples are read again (they were staged a batch ago:
+// L2 holds them), all eight loads in flight before the first conversion.
+template <int CONV>
+__device__ __forceinline__ void dc_magnitudes_half (const DcParams &p, const float *uc8f, const float *zI, const float *zQ,
+                                                    long long b, int off, int cnt, long long c1, int lane)
+{
+  constexpr int kGo = kDcBatch / 2 / 256;
+  DcRaw<CONV> raw[kGo];
+#pragma unroll
+  for (int g = 0; g < kGo; g++) dc_load4<CONV> (p.iq, b + off + 256 * g + 4 * lane, c1, raw[g]);
+#pragma unroll
+  for (int g = 0; g < kGo; g++) {
+    const int o = off + 256 * g + 4 * lane;
+    if (o >= cnt) break;
+    float fI[4], fQ[4];
+    dc_to_float<CONV> (raw[g], uc8f, fI, fQ);
+    const float4 a = *reinterpret_cast<const float4 *> (zI + o);
+    const float4 c = *reinterpret_cast<const float4 *> (zQ + o);
+    const float zi[4] = { a.x, a.y, a.z, a.w }, zq[4] = { c.x, c.y, c.z, c.w };
+    uint32_t m[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      m[k] = mag_from_float (__fsub_rn (fI[k], zi[k]), __fsub_rn (fQ[k], zq[k]), nullptr);
+    uint16_t *dst = p.mag + b + o;
+    if (o + 4 <= cnt) {
+      uint32_t *d32 = reinterpret_cast<uint32_t *> (dst);          // p.mag is 4-byte aligned, b and o are even
+      d32[0] = m[0] | (m[1] << 16); d32[1] = m[2] | (m[3] << 16);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) if (o + k < cnt) dst[k] = uint16_t (m[k]);
+    }
+  }
+}
+
+// One workgroup per chunk.  Waves 0 / 2 run the chains I-lo / Q-lo, waves 1 / 3 the chains I-hi / Q-hi until their
+// bracket has closed -- which it has, for all but a few chunks, before the chunk's own samples begin.  From then on the
+// two hi waves have nothing to step, and form the magnitudes of the batch BEFORE the one the lo waves are stepping: the
+// lo chains write z1 over the t values they have consumed (same LDS slot, same lane), two batch buffers alternate, and
+// the magnitude work (as long as a batch's chain rounds) leaves the critical path.  A batch of the chunk's own samples
+// stepped while a bracket was still open gets no magnitudes here: the host steps [first sample, closed_at) again from
+// the exact state (prepare_dc), brackets closed from the start.
 template <int CONV>
 __global__ __launch_bounds__ (256)
 void dc_chain_kernel (const DcParams p)
 {
-  __shared__ __attribute__ ((aligned (16))) float s_t[2][kDcBatchLds];   // f * DC_A per channel
-  __shared__ __attribute__ ((aligned (16))) float s_z[2][kDcBatchLds];   // z1 behind every sample, lo chains (the hi chains only serve to close the brackets)
+  __shared__ __attribute__ ((aligned (16))) float s_buf[2][2][kDcBatchLds];   // [batch parity][channel]: f * DC_A, then z1 in place
   __shared__ float s_uc8[256];
   __shared__ float s_state[4];                                        // I-lo, I-hi, Q-lo, Q-hi behind the last batch
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane (tid >> 6);
   const DcChunk d = p.desc[blockIdx.x];
   if (CONV == kConvUc8Generic) s_uc8[tid] = float ((double (tid) - 127.5) / 127.5);       // ref: src/convert.c:131
   if (tid == 0) { s_state[0] = d.zIlo; s_state[1] = d.zIhi; s_state[2] = d.zQlo; s_state[3] = d.zQhi; }
@@ -191,23 +274,28 @@ void dc_chain_kernel (const DcParams p)
   float z = wv == 0 ? d.zIlo : wv == 1 ? d.zIhi : wv == 2 ? d.zQlo : d.zQhi;
   const float A = p.A, B = p.B;
   uint32_t n_guess = 0, n_plain = 0;
+  float leak_adj = 0.0f;
   long long tm_chain = 0, tm_bar = 0, tm_total = clock64 ();
 
   constexpr int NG = kDcBatch / 1024;                                // groups of 1024 samples: four per thread each
   DcRaw<CONV> raw[NG];
 #pragma unroll
   for (int g = 0; g < NG; g++) dc_load4<CONV> (p.iq, d.start + 1024 * g + 4 * tid, c1, raw[g]);
-  for (long long b = d.start; b < c1; b += kDcBatch) {
-    float fI[NG][4], fQ[NG][4];
+  int pb = 0;                                                        // parity of the batch being stepped
+  bool prev_ok = false;                                              // the batch before holds z1 of both channels and wants magnitudes
+  long long prev_b = 0;
+  int prev_cnt = 0;
+  for (long long b = d.start; b < c1; b += kDcBatch, pb ^= 1) {
 #pragma unroll
     for (int g = 0; g < NG; g++) {
-      dc_to_float<CONV> (raw[g], s_uc8, fI[g], fQ[g]);
+      float fI[4], fQ[4];
+      dc_to_float<CONV> (raw[g], s_uc8, fI, fQ);
       if (b + kDcBatch < c1) dc_load4<CONV> (p.iq, b + kDcBatch + 1024 * g + 4 * tid, c1, raw[g]);   // next batch, in flight behind the chains
       float4 tI, tQ;
-      tI.x = __fmul_rn (fI[g][0], A); tI.y = __fmul_rn (fI[g][1], A); tI.z = __fmul_rn (fI[g][2], A); tI.w = __fmul_rn (fI[g][3], A);
-      tQ.x = __fmul_rn (fQ[g][0], A); tQ.y = __fmul_rn (fQ[g][1], A); tQ.z = __fmul_rn (fQ[g][2], A); tQ.w = __fmul_rn (fQ[g][3], A);
-      *reinterpret_cast<float4 *> (&s_t[0][dcp (1024 * g + 4 * tid)]) = tI;
-      *reinterpret_cast<float4 *> (&s_t[1][dcp (1024 * g + 4 * tid)]) = tQ;
+      tI.x = __fmul_rn (fI[0], A); tI.y = __fmul_rn (fI[1], A); tI.z = __fmul_rn (fI[2], A); tI.w = __fmul_rn (fI[3], A);
+      tQ.x = __fmul_rn (fQ[0], A); tQ.y = __fmul_rn (fQ[1], A); tQ.z = __fmul_rn (fQ[2], A); tQ.w = __fmul_rn (fQ[3], A);
+      *reinterpret_cast<float4 *> (&s_buf[pb][0][dcp (1024 * g + 4 * tid)]) = tI;
+      *reinterpret_cast<float4 *> (&s_buf[pb][1][dcp (1024 * g + 4 * tid)]) = tQ;
     }
     // the states the chains hold in front of this batch
     const float sIlo = s_state[0], sIhi = s_state[1], sQlo = s_state[2], sQhi = s_state[3];
@@ -215,52 +303,44 @@ void dc_chain_kernel (const DcParams p)
     __syncthreads ();
     tm_bar += clock64 () - tb;
     const bool region = b >= c0;
+    const bool both_closed = sIlo == sIhi && sQlo == sQhi;
     if (b == c0 && tid == 0) {            // first sample of the chunk: have the brackets closed?
       float *zs = p.z_start + 4 * size_t (d.slot);
       zs[0] = sIlo; zs[1] = sIhi; zs[2] = sQlo; zs[3] = sQhi;
-      p.unmerged[d.slot] = (sIlo == sIhi && sQlo == sQhi) ? 0u : 1u;
+      p.unmerged[d.slot] = both_closed ? 0u : 1u;
     }
-    if (region && !noted && sIlo == sIhi && sQlo == sQhi) {       // from here on the chunk's values are final
+    if (region && !noted && both_closed) {                          // from here on the chunk's values are final
       noted = true;
       if (tid == 0) { p.closed_at[d.slot] = b; p.z_close[2 * size_t (d.slot)] = sIlo; p.z_close[2 * size_t (d.slot) + 1] = sQlo; }
     }
     const int cnt = int (min ((long long) kDcBatch, c1 - b));
     const bool closed = (wv & 1) && (wv == 1 ? sIlo == sIhi : sQlo == sQhi);     // a hi chain that has met its lo chain
+    const bool keep_z = region && both_closed;                      // the lo chains leave z1 in the batch buffer
     if (!closed) {
       const long long tc = clock64 ();
-      z = dc_chain_batch (s_t[wv >> 1], s_z[wv >> 1], !(wv & 1), cnt, z, B, lane, n_guess, n_plain);
+      float *t = s_buf[pb][wv >> 1];
+      z = dc_chain_batch (t, t, !(wv & 1) && keep_z, cnt, z, B, lane, n_guess, n_plain, leak_adj);
       if (lane == 0) {
         s_state[wv] = z;
         if (!(wv & 1) && (wv == 0 ? sIlo == sIhi : sQlo == sQhi)) s_state[wv + 1] = z;   // the closed hi chain follows
       }
       tm_chain += clock64 () - tc;
+    } else if (prev_ok) {
+      // (prev_ok implies both hi waves are closed: brackets do not open again)
+      dc_magnitudes_half<CONV> (p, s_uc8, s_buf[pb ^ 1][0], s_buf[pb ^ 1][1], prev_b, (wv >> 1) * (kDcBatch / 2), prev_cnt, c1, lane);
     }
     tb = clock64 ();
     __syncthreads ();
     tm_bar += clock64 () - tb;
     if (closed) z = s_state[wv];
-    if (region) {
-#pragma unroll
-      for (int g = 0; g < NG; g++) {
-        const int o = 1024 * g + 4 * tid;
-        if (o >= cnt) break;
-        const float4 zI = *reinterpret_cast<const float4 *> (&s_z[0][dcp (o)]);
-        const float4 zQ = *reinterpret_cast<const float4 *> (&s_z[1][dcp (o)]);
-        const float zi[4] = { zI.x, zI.y, zI.z, zI.w }, zq[4] = { zQ.x, zQ.y, zQ.z, zQ.w };
-        uint32_t m[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++)                                // ref: src/convert.c:139-147
-          m[k] = mag_from_float (__fsub_rn (fI[g][k], zi[k]), __fsub_rn (fQ[g][k], zq[k]), nullptr);
-        uint16_t *dst = p.mag + b + o;
-        if (o + 4 <= cnt) {
-          uint32_t *d32 = reinterpret_cast<uint32_t *> (dst);      // p.mag is 4-byte aligned, b and o are even
-          d32[0] = m[0] | (m[1] << 16); d32[1] = m[2] | (m[3] << 16);
-        } else {
-#pragma unroll
-          for (int k = 0; k < 4; k++) if (o + k < cnt) dst[k] = uint16_t (m[k]);
-        }
-      }
-    }
+    prev_ok = keep_z; prev_b = b; prev_cnt = cnt;
+  }
+  if (prev_ok) {                          // the last batch: every wave takes a quarter
+    const int half = (wv >> 1) * (kDcBatch / 2), quarter = (wv & 1) * (kDcBatch / 4);
+    // a half is eight goes of 256 samples; waves 0 / 2 take goes 0..3 of their half, waves 1 / 3 goes 4..7
+    const int cnt_q = min (prev_cnt, half + quarter + kDcBatch / 4);
+    if (half + quarter < prev_cnt)
+      dc_magnitudes_half<CONV> (p, s_uc8, s_buf[pb ^ 1][0], s_buf[pb ^ 1][1], prev_b, half + quarter, cnt_q, c1, lane);
   }
   __syncthreads ();
   if (tid == 0) {
