@@ -230,6 +230,7 @@ struct DcParams {
   float           A, B;        // convert_state.DC_A, DC_B (ref: src/convert.c:349-353)
   const DcChunk  *desc;        // one per launched wave
   uint16_t       *mag;         // [n] magnitudes of the shard's samples (4-byte aligned)
+  float          *mag_sq;      // [n] the clamped squared magnitudes `power += mag_sq` adds up (ref: src/convert.c:142-146), or null (16-byte aligned)
   float          *z_start;     // [slots][4] I-lo, I-hi, Q-lo, Q-hi in front of the chunk's first sample
   float          *z_end;       // [slots][2] z1_I, z1_Q behind the last sample stepped
   uint32_t       *unmerged;    // [slots] 1 = the bracket was still open at the chunk's first sample

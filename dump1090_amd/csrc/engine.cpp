@@ -222,6 +222,7 @@ struct modes_engine {
   uint32_t cap = 0;
   // float converters with the DC block on (kernels_dc.hip): V = [overlap | magnitudes] of the shard in HBM
   DevBuf<uint16_t> dc_mag;
+  DevBuf<float> dc_sq;                 // squared magnitudes of a filter_dc run with compute_power (what mean_power adds up)
   DevBuf<DcChunk> dc_desc;
   DevBuf<float> dc_zs, dc_ze;
   DevBuf<uint32_t> dc_unm;
@@ -416,8 +417,8 @@ int prepare_dc (modes_engine *e, const void *d_iq, size_t nbytes, const uint16_t
   // RN (z * B) = z - k ulp with k an integer, so the float filter's leak is off by up to half an ulp per step, which
   // the filter itself turns into at most 0.5 ulp / DC_A <= |z| / m.  A bracket that wide closes after about
   // ln (2 / m * 2^24) / DC_A samples (13.5 time constants at 2.4 MS/s).  Chunks still open at their first sample are
-  // repaired below (only up to where they closed), so the length trades warm-up steps against repairs: 15.
-  double warm_tau = 15.0;
+  // repaired below (only up to where they closed), so the length trades warm-up steps against repairs: 12 (measured on the bench recording and on the same without frames: 9 to 14 within 4 %, below 9 whole chunks never close).
+  double warm_tau = 12.0;
   if (const char *ev = getenv ("MODES_DC_WARM_TAU")) if (atof (ev) > 0) warm_tau = atof (ev);
   uint64_t warm = e->dc_warm ? e->dc_warm : uint64_t (std::ceil (warm_tau / double (e->dc_A)));
   warm = (warm + kDcBatch - 1) / kDcBatch * kDcBatch;
@@ -475,6 +476,10 @@ int prepare_dc (modes_engine *e, const void *d_iq, size_t nbytes, const uint16_t
   q.iq = static_cast<const uint8_t *> (d_iq) - back * bps;
   q.n = n_eff; q.chunk_len = L; q.A = e->dc_A; q.B = e->dc_B;
   q.desc = e->dc_desc.p; q.mag = V + ov - back;
+  if ((e->cfg.compute_power || e->cfg.mode_ac) && e->mode == 2400) {      // mean_power is only read by demod_2400's noise statistics and demod_2400_AC
+    if ((rc = e->dc_sq.reserve (size_t (n_eff) + 1024)) != MODES_OK) return rc;
+    q.mag_sq = e->dc_sq.p;
+  }
   q.z_start = e->dc_zs.p; q.z_end = e->dc_ze.p; q.unmerged = e->dc_unm.p; q.closed_at = e->dc_closed.p; q.z_close = e->dc_zc.p;
   q.rounds = reinterpret_cast<unsigned long long *> (e->dc_unm.p + ((2 * K + 2) & ~1ull));
   HIP_TRY (hipMemsetAsync (q.rounds, 0, 6 * sizeof (unsigned long long), stream));
@@ -579,6 +584,14 @@ int prepare_dc (modes_engine *e, const void *d_iq, size_t nbytes, const uint16_t
     e->dc_info.rerun_chunks++;
   }
   e->dc_z[0] = ze[2 * (K - 1)]; e->dc_z[1] = ze[2 * (K - 1) + 1];
+  if (q.mag_sq) {
+    // mag_buf.mean_power of every block: the converter's float running sum over the block's squared magnitudes, in
+    // sample order (ref: src/convert.c:146,153-154) -- formed from the values the chain kernel left, repairs included
+    const uint32_t nblocks = uint32_t ((n + e->block_samples - 1) / e->block_samples);
+    if ((rc = e->block_power.reserve (nblocks)) != MODES_OK) return rc;
+    HIP_TRY (launch_dc_block_power (q.mag_sq + back, n, e->block_samples, nblocks, e->block_power.p, stream));
+    e->nblocks_power = nblocks;
+  }
   return MODES_OK;
 }
 
@@ -866,8 +879,6 @@ int modes_engine_create (const modes_engine_config *cfg, modes_engine **out)
   const int conv = select_converter (cfg->input_format, cfg->filter_dc != 0, cfg->compute_power != 0);
   if (conv < 0) return fail (MODES_E_ARG, "no suitable converter for format=%d power=%d DC=%d", cfg->input_format,
                              cfg->compute_power, cfg->filter_dc);
-  if (cfg->filter_dc && cfg->mode_ac && cfg->sample_rate == 2400000)
-    return fail (MODES_E_ARG, "demod_2400_AC behind a DC-filter converter is not built (block mean_power)");
   int ndev = 0;
   if (hipGetDeviceCount (&ndev) != hipSuccess || ndev <= 0) return fail (MODES_E_NODEVICE, "no HIP device");
   if (cfg->device < 0 || cfg->device >= ndev) return fail (MODES_E_ARG, "device %d of %d", cfg->device, ndev);
@@ -910,7 +921,7 @@ void modes_engine_destroy (modes_engine *e)
   if (e->pin_text) (void) hipHostFree (e->pin_text);
   e->dc_lin.release (); e->dc_ticks.release (); e->dc_zc.release (); e->dc_closed.release ();
   for (hipEvent_t ev : e->dc_ev) if (ev) (void) hipEventDestroy (ev);
-  e->dc_mag.release (); e->dc_desc.release (); e->dc_zs.release (); e->dc_ze.release (); e->dc_unm.release ();
+  e->dc_mag.release (); e->dc_sq.release (); e->dc_desc.release (); e->dc_zs.release (); e->dc_ze.release (); e->dc_unm.release ();
   e->d8_trig.release (); e->d8_amb.release (); e->d8_off.release (); e->d8_p0.release (); e->d8_mx.release ();
   e->d8_win_count.release (); e->d8_chunk_rec.release (); e->d8_announce.release (); e->d8_table.release (); e->d8_entry.release ();
   e->d8_win_start.release (); e->d8_small.release (); e->d8_windows.release (); e->d8_win_packed.release ();
@@ -977,6 +988,7 @@ static int run_device_inner (modes_engine *e, const void *d_iq, size_t nbytes, u
   ScanParams sp;
   int rc = fill_scan_params (e, d_iq, nbytes, d_halo, &sp);
   if (rc != MODES_OK) return rc;
+  e->nblocks_power = 0;
   if (e->cfg.filter_dc && (rc = prepare_dc (e, d_iq, nbytes, d_halo, stream, &sp)) != MODES_OK) return rc;
   if (sp.nstrips == 0) return MODES_OK;
   // A strip that holds more candidates than its slots is reported, never cut short: scan again with four times the
@@ -984,7 +996,6 @@ static int run_device_inner (modes_engine *e, const void *d_iq, size_t nbytes, u
   const uint32_t cap_max = e->mode == 2000 ? 3u * kStrip : uint32_t (kStrip);
   std::vector<uint32_t> cache_in (e->cache.raw (), e->cache.raw () + kIcaoSlots);      // an overflowed attempt may have touched it
   e->tail_half ^= 1;                        // once per run: a rescan writes the same half again
-  e->nblocks_power = 0;
   if (e->mode == 2400 && e->cfg.compute_power && !e->cfg.filter_dc && !e->cfg.mode_ac) {
     // Modes.measure_noise: demod_2400 reads mag_buf.mean_power of every block (ref: src/demod-2400.c:524-530)
     const uint32_t nblocks = uint32_t ((sp.nsamples + e->block_samples - 1) / e->block_samples);
@@ -1151,10 +1162,20 @@ static int run_mode_ac_2400 (modes_engine *e, const void *d_iq, size_t nbytes, u
   if (sp.nstrips == 0) return MODES_OK;
   const uint32_t B = e->block_samples;
   const uint32_t nblocks = uint32_t ((sp.nsamples + B - 1) / B);
-  if ((rc = e->block_power.reserve (nblocks)) != MODES_OK) return rc;
   if ((rc = e->noise_level.reserve (nblocks)) != MODES_OK) return rc;
-  HIP_TRY (launch_block_power (sp, nblocks, e->block_power.p, stream));
-  e->nblocks_power = nblocks;
+  if (e->cfg.filter_dc) {
+    // the Mode S pass before this one left the magnitudes of the whole shard (DC block applied) and, with
+    // compute_power, every block's mean_power: read those (prepare_dc)
+    if (!e->dc_mag.p) return fail (MODES_E_ARG, "demod_2400_AC: no filter_dc magnitudes to read");
+    sp.iq = reinterpret_cast<const uint8_t *> (e->dc_mag.p + 8);
+    sp.conv = kConvMagU16; sp.navail = sp.nsamples + e->ov; sp.halo = nullptr;
+    // (the float converters report their power sum whether or not it was asked for: ref: src/convert.c:146,153-154)
+    if (e->nblocks_power != nblocks) return fail (MODES_E_ARG, "demod_2400_AC: the filter_dc run left no block powers");
+  } else {
+    if ((rc = e->block_power.reserve (nblocks)) != MODES_OK) return rc;
+    HIP_TRY (launch_block_power (sp, nblocks, e->block_power.p, stream));
+    e->nblocks_power = nblocks;
+  }
   HIP_TRY (launch_noise_level (e->block_power.p, nblocks, e->noise_level.p, stream));
   sp.noise_level = e->noise_level.p;
   uint64_t *d_totals = reinterpret_cast<uint64_t *> (e->d_stats);

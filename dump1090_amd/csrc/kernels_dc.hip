@@ -235,9 +235,14 @@ __device__ __forceinline__ void dc_magnitudes_half (const DcParams &p, const flo
     const float4 c = *reinterpret_cast<const float4 *> (zQ + o);
     const float zi[4] = { a.x, a.y, a.z, a.w }, zq[4] = { c.x, c.y, c.z, c.w };
     uint32_t m[4];
+    float sq[4];
 #pragma unroll
     for (int k = 0; k < 4; k++)
-      m[k] = mag_from_float (__fsub_rn (fI[k], zi[k]), __fsub_rn (fQ[k], zq[k]), nullptr);
+      m[k] = mag_from_float (__fsub_rn (fI[k], zi[k]), __fsub_rn (fQ[k], zq[k]), &sq[k]);
+    if (p.mag_sq) {                      // b and o are multiples of 4: whole float4s (the slack behind [n] takes the ragged end)
+      float4 q4; q4.x = sq[0]; q4.y = sq[1]; q4.z = sq[2]; q4.w = sq[3];
+      *reinterpret_cast<float4 *> (p.mag_sq + b + o) = q4;
+    }
     uint16_t *dst = p.mag + b + o;
     if (o + 4 <= cnt) {
       uint32_t *d32 = reinterpret_cast<uint32_t *> (dst);          // p.mag is 4-byte aligned, b and o are even
@@ -391,6 +396,68 @@ void dc_linear_kernel (const uint8_t *iq, long long n, double A, double B, doubl
   if ((tid & 63) == 0) { s_part[0][tid >> 6] = aI; s_part[1][tid >> 6] = aQ; }
   __syncthreads ();
   if (tid < 2) out[2 * size_t (blockIdx.x) + tid] = A * (s_part[tid][0] + s_part[tid][1] + s_part[tid][2] + s_part[tid][3]);
+}
+
+// ---- mean_power of every block from the stored squared magnitudes ----------------------------------------------
+// `power += mag_sq` (ref: src/convert.c:146,153-154) is a float running sum over the block's samples, in order: the
+// result depends on that order.  One wave per block; like the chains above, every lane adds its own sixteen values from
+// a guessed start, a lane is proven when its start IS, bit for bit, what the lane below ended on, and the others take
+// the proven front plus the increments in between -- at least one more lane is proven with every pass.
+__global__ __launch_bounds__ (256)
+void dc_block_power_kernel (const float *sq, uint64_t n, uint32_t block_samples, uint32_t nblocks, double *mean_power)
+{
+  const uint32_t blk = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (blk >= nblocks) return;
+  const uint64_t n0 = uint64_t (blk) * block_samples, n1 = min (n0 + uint64_t (block_samples), n);
+  float p0 = 0.0f;
+  uint64_t base = n0;
+  while (base < n1) {
+    const uint64_t rem = n1 - base;
+    if (rem < 16) {                                    // ragged end: plain adds
+      for (uint64_t i = 0; i < rem; i++) p0 = __fadd_rn (p0, sq[base + i]);
+      break;
+    }
+    const int nl = rem >= 1024 ? 64 : int (rem / 16);
+    float x[16];
+    if (lane < nl) {
+      const float4 *src = reinterpret_cast<const float4 *> (sq + base + 16 * lane);        // base stays a multiple of 16 floats
+#pragma unroll
+      for (int g = 0; g < 4; g++) { const float4 v = src[g]; x[4 * g] = v.x; x[4 * g + 1] = v.y; x[4 * g + 2] = v.z; x[4 * g + 3] = v.w; }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; q++) x[q] = 0.0f;
+    }
+    float tot = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; q++) tot += x[q];
+    float start = p0 + (wave_incl_scan_f (tot) - tot);
+    float pe = 0.0f;
+    for (;;) {
+      float v = start;
+#pragma unroll
+      for (int q = 0; q < 16; q++) v = __fadd_rn (v, x[q]);
+      float below = __uint_as_float (dpp_mov<0x138, 0xF, true> (__float_as_uint (v)));
+      if (lane == 0) below = p0;
+      const u64 bad = __ballot (__float_as_uint (below) != __float_as_uint (start) && lane < nl);
+      const int good = bad ? __builtin_ctzll (bad) : nl;
+      if (good == nl) { pe = bcast_lane (v, nl - 1); break; }
+      const float pg = bcast_lane (v, good - 1);
+      const float inc = lane >= good ? __fsub_rn (v, start) : 0.0f;
+      const float incl = wave_incl_scan_f (inc);
+      if (lane >= good) start = __fadd_rn (pg, __fsub_rn (incl, inc));
+    }
+    p0 = pe;
+    base += 16ull * nl;
+  }
+  if (lane == 0) mean_power[blk] = double (p0);
+}
+
+hipError_t launch_dc_block_power (const float *sq, uint64_t n, uint32_t block_samples, uint32_t nblocks, double *mean_power, hipStream_t stream)
+{
+  if (nblocks == 0) return hipSuccess;
+  hipLaunchKernelGGL (dc_block_power_kernel, dim3 ((nblocks + 3) / 4), dim3 (256), 0, stream, sq, n, block_samples, nblocks, mean_power);
+  return hipGetLastError ();
 }
 
 hipError_t launch_dc_linear (int conv, const uint8_t *iq, uint64_t n, double A, double B, double *out, hipStream_t stream)

@@ -120,9 +120,20 @@ def test_long_recording_brackets_close():
     assert e.get_dc_state() == zexp
     # nearly all chunks are right as first stepped; the few whose bracket closed late are repaired
     assert info["chunks"] >= 128 and info["rerun_chunks"] + info["prefix_reruns"] <= info["chunks"] // 10, info
-    emsg, _ = oracle_run(iq, "uc8", filter_dc=True, compute_power=True)
+    o = orc.Oracle(2400000, fix_bits=1, measure_noise=True)
+    o.run_stream(iq, orc.INPUT_UC8, 2400, filter_dc=True, compute_power=True)
+    emsg, est = o.messages(), o.stats()
     assert len(emsg) > 5000
     assert_same_messages(e.messages(), emsg)
+    # mag_buf.mean_power of every block: the converter's float running sum in sample order (ref: src/convert.c:146,153-154),
+    # bit for bit, and with it Modes.stat.noise_power_* of the reference's shipped configuration (DC-filter = true,
+    # measure-noise = true; ref: src/demod-2400.c:524-530)
+    bp = e.block_power()
+    assert len(bp) == len(o.last_block_power) == -(-n // 131072) and np.array_equal(bp, o.last_block_power)
+    ps = e.power_stats()
+    assert ps["noise_valid"] == 1 and ps["noise_power_count"] == est["noise_power_count"]
+    np.testing.assert_allclose(ps["noise_power_sum"], est["noise_power_sum"], rtol=1e-9)
+    np.testing.assert_allclose(ps["signal_power_sum"], est["signal_power_sum"], rtol=1e-9)
 
     # a shard decoded on its own: 14 M samples of lead-in settle the filter, the lead-in also yields the overlap
     first = 153 * 131072
@@ -133,8 +144,33 @@ def test_long_recording_brackets_close():
     got = s.dc_magnitudes(0, 326 + n - first)
     assert np.array_equal(got, exp[first - 326:])
     assert s.get_dc_state() == zexp
+    assert np.array_equal(s.block_power(), o.last_block_power[153:])            # ... and the shard's blocks their powers
 
     # ... and a lead-in that is too short is refused, not guessed
     s.set_dc_lead(65536)
     with pytest.raises(da.ModesError):
         s.run_device(iq_t.data_ptr() + 2 * first, iq.nbytes - 2 * first, first_sample=first)
+
+
+def test_mode_ac_behind_the_dc_converter():
+    """demod_2400 + demod_2400_AC per block with the DC block on: the Mode A/C pass reads the magnitudes and the block
+    powers the DC chain left (its threshold comes from mag_buf.mean_power, ref: src/demod-2400AC.c:34-35)."""
+    from test_gpu_parity_2400ac import mode_a_stream
+    iq16, _ = mode_a_stream(65536 * 5 + 999, 8, mode_s=0.5)
+    # the same signal as uc8 with a DC offset (what the DC block is for)
+    x = iq16.astype(np.float64) / 32767.0
+    x[0::2] += 0.02
+    x[1::2] -= 0.015
+    iq = np.clip(np.round(x * 127.5 + 127.5), 0, 255).astype(np.uint8)
+    for power in (False, True):
+        o = orc.Oracle(2400000, fix_bits=1, mode_ac=False, measure_noise=power)
+        o.run_stream(iq, orc.INPUT_UC8, 2400, filter_dc=True, compute_power=power, also_ac=True)
+        exp, est = o.messages(), o.stats()
+        e = da.Engine(2400000, da.INPUT_UC8, filter_dc=True, compute_power=power, mode_ac=True)
+        e.run_host(iq)
+        got, gst = e.messages(), e.stats()
+        assert (exp["msg_type"] == 17).sum() > 50
+        assert_same_messages(got, exp)
+        for k in ("valid_preamble", "demod_modeac", "demodulated", "CRC_good"):
+            assert gst[k] == est[k], k
+        assert np.array_equal(e.block_power(), o.last_block_power)
