@@ -230,6 +230,8 @@ struct modes_engine {
   DevBuf<float> dc_zc;
   DevBuf<long long> dc_closed;
   DevBuf<unsigned long long> dc_ticks;
+  hipEvent_t dc_power_done = nullptr;        // the block powers of a filter_dc run are formed beside the scan
+  bool dc_power_pending = false;
   hipEvent_t dc_ev[4] = { nullptr, nullptr, nullptr, nullptr };   // around the chain launch / around each repair launch
   float dc_A = 0.0f, dc_B = 1.0f, dc_z[2] = { 0.0f, 0.0f };
   uint64_t dc_lead = 0, dc_warm = 0;
@@ -417,8 +419,8 @@ int prepare_dc (modes_engine *e, const void *d_iq, size_t nbytes, const uint16_t
   // RN (z * B) = z - k ulp with k an integer, so the float filter's leak is off by up to half an ulp per step, which
   // the filter itself turns into at most 0.5 ulp / DC_A <= |z| / m.  A bracket that wide closes after about
   // ln (2 / m * 2^24) / DC_A samples (13.5 time constants at 2.4 MS/s).  Chunks still open at their first sample are
-  // repaired below (only up to where they closed), so the length trades warm-up steps against repairs: 12 (measured on the bench recording and on the same without frames: 9 to 14 within 4 %, below 9 whole chunks never close).
-  double warm_tau = 12.0;
+  // repaired below (only up to where they closed), so the length trades warm-up steps against repairs: 14 (measured on the bench recording and on the same without frames: 9 to 14 within 4 %, below 9 whole chunks never close).
+  double warm_tau = 14.0;
   if (const char *ev = getenv ("MODES_DC_WARM_TAU")) if (atof (ev) > 0) warm_tau = atof (ev);
   uint64_t warm = e->dc_warm ? e->dc_warm : uint64_t (std::ceil (warm_tau / double (e->dc_A)));
   warm = (warm + kDcBatch - 1) / kDcBatch * kDcBatch;
@@ -589,7 +591,13 @@ int prepare_dc (modes_engine *e, const void *d_iq, size_t nbytes, const uint16_t
     // sample order (ref: src/convert.c:146,153-154) -- formed from the values the chain kernel left, repairs included
     const uint32_t nblocks = uint32_t ((n + e->block_samples - 1) / e->block_samples);
     if ((rc = e->block_power.reserve (nblocks)) != MODES_OK) return rc;
-    HIP_TRY (launch_dc_block_power (q.mag_sq + back, n, e->block_samples, nblocks, e->block_power.p, stream));
+    // (a bandwidth-bound pass that nothing in the decode reads: on a stream of its own, beside the scan kernel; the host
+    // has waited for the chain above, and the caller's stream waits for this kernel before the run is over)
+    if (!e->copy_stream) HIP_TRY (hipStreamCreateWithFlags (&e->copy_stream, hipStreamNonBlocking));
+    if (!e->dc_power_done) HIP_TRY (hipEventCreateWithFlags (&e->dc_power_done, hipEventDisableTiming));
+    HIP_TRY (launch_dc_block_power (q.mag_sq + back, n, e->block_samples, nblocks, e->block_power.p, e->copy_stream));
+    HIP_TRY (hipEventRecord (e->dc_power_done, e->copy_stream));
+    e->dc_power_pending = true;
     e->nblocks_power = nblocks;
   }
   return MODES_OK;
@@ -921,6 +929,7 @@ void modes_engine_destroy (modes_engine *e)
   if (e->pin_text) (void) hipHostFree (e->pin_text);
   e->dc_lin.release (); e->dc_ticks.release (); e->dc_zc.release (); e->dc_closed.release ();
   for (hipEvent_t ev : e->dc_ev) if (ev) (void) hipEventDestroy (ev);
+  if (e->dc_power_done) (void) hipEventDestroy (e->dc_power_done);
   e->dc_mag.release (); e->dc_sq.release (); e->dc_desc.release (); e->dc_zs.release (); e->dc_ze.release (); e->dc_unm.release ();
   e->d8_trig.release (); e->d8_amb.release (); e->d8_off.release (); e->d8_p0.release (); e->d8_mx.release ();
   e->d8_win_count.release (); e->d8_chunk_rec.release (); e->d8_announce.release (); e->d8_table.release (); e->d8_entry.release ();
@@ -1729,6 +1738,10 @@ int modes_engine_run_device (modes_engine *e, const void *d_iq, size_t nbytes, u
   if (!e || (!d_iq && nbytes)) return fail (MODES_E_ARG, "null argument");
   if (e->mode == 8000) return run_8000 (e, d_iq, nbytes, first_sample, d_halo, static_cast<hipStream_t> (stream_v));
   int rc = run_device_inner (e, d_iq, nbytes, first_sample, d_halo, stream_v);
+  if (e->dc_power_pending) {               // the block powers of a filter_dc run: formed beside the scan, done when the caller's stream is
+    e->dc_power_pending = false;
+    HIP_TRY (hipStreamWaitEvent (static_cast<hipStream_t> (stream_v), e->dc_power_done, 0));
+  }
   if (rc == MODES_OK && e->mode == 2400 && e->cfg.mode_ac)
     rc = run_mode_ac_2400 (e, d_iq, nbytes, first_sample, d_halo, static_cast<hipStream_t> (stream_v));
   return rc;
@@ -1863,6 +1876,7 @@ int modes_engine_get_power_stats (modes_engine *e, modes_power_stats *out)
   if (e->cfg.compute_power && e->nblocks_power) {     // Modes.measure_noise: mean_power of every block was formed with the run
     std::vector<double> pw (e->nblocks_power);
     HIP_TRY (hipSetDevice (e->cfg.device));
+    if (e->dc_power_done) HIP_TRY (hipEventSynchronize (e->dc_power_done));
     HIP_TRY (hipMemcpy (pw.data (), e->block_power.p, pw.size () * sizeof (double), hipMemcpyDeviceToHost));
     for (size_t b = 0; b < pw.size (); b++) {
       out->noise_power_sum += pw[b] - (b < blk_signal.size () ? blk_signal[b] : 0.0);
@@ -2025,6 +2039,7 @@ size_t modes_engine_block_power (modes_engine *e, double *out, size_t max)
   const size_t n = e->nblocks_power;
   if (out && n) {
     if (hipSetDevice (e->cfg.device) != hipSuccess) return 0;
+    if (e->dc_power_done && hipEventSynchronize (e->dc_power_done) != hipSuccess) return 0;
     if (hipMemcpy (out, e->block_power.p, (n < max ? n : max) * sizeof (double), hipMemcpyDeviceToHost) != hipSuccess) return 0;
   }
   return n;
