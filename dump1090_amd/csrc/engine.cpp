@@ -176,6 +176,7 @@ struct modes_engine {
   DevBuf<uint32_t> dirty, blk_wrote;
   hipStream_t post_stream = nullptr;          // ordered pass and emit of one range of blocks while the next is scanned
   hipStream_t copy_stream = nullptr;          // read-back of a range's messages
+  hipStream_t emit_stream = nullptr;          // a range's emit, between its ordered pass and its read-back
   std::vector<hipEvent_t> emit_events;        // one per range: its messages are formed
   std::vector<hipEvent_t> range_events;       // two per range: around its scan
   size_t last_nm = 0;                         // messages of the last run: what the next run's buffers start with
@@ -184,7 +185,9 @@ struct modes_engine {
   // what the host reads once per accept round, in one copy: 32 totals (u64), 64 `changed` words (one per round), the
   // ICAO cache behind the range's last block
   DevBuf<uint32_t> rb;
-  PinBuf<uint32_t> pin_rb;
+  PinBuf<uint32_t> pin_rb;             // two landing areas: a round is queued while the one before is read
+  hipEvent_t round_ev[2] = { nullptr, nullptr };
+  PinBuf<uint32_t> pin_entry;          // the ICAO cache a range is entered with, where a kernel can fetch it
   DevBuf<D8Window> d8_windows, d8_win_packed;
   DevBuf<Record> d8_records, d8_rec_packed;
   PinBuf<D8Window> pin_wins;
@@ -652,7 +655,7 @@ int reserve_messages (modes_engine *e, size_t need, size_t keep)
   return MODES_OK;
 }
 
-constexpr uint32_t kRbTotals = 0, kRbChanged = 64, kRbRounds = 64, kRbCache = kRbChanged + kRbRounds, kRbWords = kRbCache + kIcaoSlots;
+constexpr uint32_t kRbTotals = 0, kRbChanged = 64, kRbRounds = 64, kRbMarked = kRbChanged + kRbRounds, kRbCache = kRbMarked + kRbRounds, kRbWords = kRbCache + kIcaoSlots;
 
 int reserve_accept_buffers (modes_engine *e, const ScanParams &sp)
 {
@@ -667,13 +670,14 @@ int reserve_accept_buffers (modes_engine *e, const ScanParams &sp)
   if ((rc = e->blk_stats.reserve (size_t (nblocks) * kBlkStats)) != MODES_OK) return rc;
   if ((rc = e->small_u32.reserve (2 * kIcaoSlots + 16)) != MODES_OK) return rc;
   if ((rc = e->rb.reserve (kRbWords)) != MODES_OK) return rc;
-  if ((rc = e->pin_rb.reserve (kRbWords)) != MODES_OK) return rc;
+  if ((rc = e->pin_rb.reserve (2 * kRbWords)) != MODES_OK) return rc;
+  if ((rc = e->pin_entry.reserve (kIcaoSlots)) != MODES_OK) return rc;
   if ((rc = e->dirty.reserve (nblocks)) != MODES_OK) return rc;
   if ((rc = e->blk_wrote.reserve (nblocks)) != MODES_OK) return rc;
   if ((rc = e->chunk_sum.reserve (nsc + 1)) != MODES_OK) return rc;
   if ((rc = e->chunk_vp.reserve (nsc + 1)) != MODES_OK) return rc;
   if ((rc = e->chunk_ovf.reserve (nsc + 1)) != MODES_OK) return rc;
-  return e->offsets.reserve (sp.nstrips);
+  return e->offsets.reserve (2 * size_t (sp.nstrips));
 }
 
 // The ordered accept pass on the device for one range of blocks whose scan is complete on `stream`: fixed-point rounds
@@ -693,9 +697,11 @@ int accept_range (modes_engine *e, const ScanParams &sp, uint64_t first_sample, 
 
   // totals of the range's scan (candidates, valid preambles, overflowed strips)
   HIP_TRY (launch_count_scan (e->counts.p + rg.strip0, e->vp_counts.p + rg.strip0, rg.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p, d_totals, stream));
-  HIP_TRY (hipMemcpyAsync (d_cache_in, e->cache.raw (), kIcaoSlots * sizeof (uint32_t), hipMemcpyHostToDevice, stream));
-  HIP_TRY (hipMemsetAsync (acc_counts, 0, size_t (rg.nstrips) * sizeof (uint32_t), stream));
-  HIP_TRY (hipMemsetAsync (d_changed, 0, kRbRounds * sizeof (uint32_t), stream));
+  // (kernels, not blits: see launch_fill_u32)
+  memcpy (e->pin_entry.p, e->cache.raw (), kIcaoSlots * sizeof (uint32_t));
+  HIP_TRY (launch_copy_u32 (d_cache_in, e->pin_entry.p, kIcaoSlots, stream));
+  HIP_TRY (launch_fill_u32 (acc_counts, rg.nstrips, 0u, stream));
+  HIP_TRY (launch_fill_u32 (d_changed, 2 * kRbRounds, 0u, stream));
   // (no per-block state is prepared: in the first round every block starts from d_cache_in, writes its delta row only
   // if it wrote a slot, and says so in blk_wrote)
 
@@ -709,31 +715,50 @@ int accept_range (modes_engine *e, const ScanParams &sp, uint64_t first_sample, 
   ap.mode = e->mode;
   ap.cache_in = d_cache_in; ap.blk_wrote = e->blk_wrote.p; ap.first_round = 1;
 
-  // Every round queues what the last round needs behind it (snapshots, totals, the cache behind the range), so the host
-  // waits once per round, for one copy, and the round that finds nothing changed is already the complete result.
-  uint32_t rounds = 0;
-  for (;;) {
-    const uint32_t slot = rounds % kRbRounds;                    // each round has its own `changed` word
-    if (rounds && slot == 0) HIP_TRY (hipMemsetAsync (d_changed, 0, kRbRounds * sizeof (uint32_t), stream));
+  // Every round queues what the last round needs behind it (snapshots, totals, the cache behind the range), so the round
+  // that finds nothing changed is already the complete result.  The host never stands between two rounds: round r + 1
+  // is queued before the host waits for what round r read back, so the device goes from round to round without the
+  // host's wake-up and launch latency in between (about 0.1 ms a round); the one round queued too many -- behind the
+  // round that found nothing changed -- looks at no block (none is dirty) and leaves every result as it is.
+  auto queue_round = [&] (uint32_t r) -> int {
+    const uint32_t slot = r % kRbRounds;                          // each round has its own `changed` word
+    if (r && slot == 0) HIP_TRY (launch_fill_u32 (d_changed, 2 * kRbRounds, 0u, stream));
     ap.changed = d_changed + slot;
+    ap.first_round = r == 0;
+    ap.dirty = r ? e->dirty.p : nullptr;                          // from the second round on
     HIP_TRY (launch_accept2400 (ap, stream));
     HIP_TRY (launch_snapshots (delta, e->blk_wrote.p + rg.blk0, nblocks, d_cache_in, e->chunk_last.p, e->chunk_entry.p, snap_in, d_cache_out, dirty,
-                               ap.changed, ap.first_round, stream));
-    ap.dirty = e->dirty.p;                                      // from the second round on
-    ap.first_round = 0;
+                               ap.changed, d_changed + kRbRounds + slot, ap.first_round, stream));
     // totals of accepted messages and the block statistics, read back together with the scan's totals
     HIP_TRY (launch_count_scan (acc_counts, e->vp_counts.p + rg.strip0, rg.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p, d_totals + 4, stream));
     HIP_TRY (launch_blk_stats_sum (blk_stats, nblocks, reinterpret_cast<unsigned long long *> (d_totals + 8), stream));
-    HIP_TRY (hipMemcpyAsync (e->pin_rb.p, e->rb.p, kRbWords * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY (hipStreamSynchronize (stream));
+    // where each strip's messages go, should this round be the last (from the chunk sums just formed; a list per round
+    // parity: the round queued behind the last one writes the other list while the emit reads this one)
+    HIP_TRY (launch_strip_offsets (acc_counts, rg.nstrips, e->chunk_sum.p, e->offsets.p + size_t (r & 1) * sp.nstrips + rg.strip0, stream));
+    HIP_TRY (launch_copy_u32 (e->pin_rb.p + (r & 1) * kRbWords, e->rb.p, kRbWords, stream));          // into pinned host memory
+    HIP_TRY (hipEventRecord (e->round_ev[r & 1], stream));
+    return MODES_OK;
+  };
+  if (!e->round_ev[0]) for (hipEvent_t &ev : e->round_ev) HIP_TRY (hipEventCreateWithFlags (&ev, hipEventDisableTiming));
+  uint32_t rounds = 0;
+  if ((rc = queue_round (0)) != MODES_OK) return rc;
+  const uint32_t *rbh = nullptr;
+  for (;;) {
+    // (a round that wraps the `changed` words clears them first: not while the round before may still set its own)
+    const bool ahead = (rounds + 1) % kRbRounds != 0;
+    if (ahead && (rc = queue_round (rounds + 1)) != MODES_OK) return rc;
+    HIP_TRY (hipEventSynchronize (e->round_ev[rounds & 1]));
+    rbh = e->pin_rb.p + (rounds & 1) * kRbWords;
+    const bool changed = rbh[kRbMarked + rounds % kRbRounds] != 0;        // a block has to run again
     rounds++;
-    if (!e->pin_rb.p[kRbChanged + slot]) break;
+    if (!changed) break;
     // a write set can only change because an earlier block's did: block k is final after round k + 1 at the latest
     if (rounds > nblocks + 2) return fail (MODES_E_HIP, "accept pass did not reach its fixed point in %u rounds", rounds);
+    if (!ahead && (rc = queue_round (rounds)) != MODES_OK) return rc;
   }
   e->stats.replay_rounds += rounds;
-  memcpy (e->cache.raw (), e->pin_rb.p + kRbCache, kIcaoSlots * sizeof (uint32_t));
-  const unsigned long long *st = reinterpret_cast<const unsigned long long *> (e->pin_rb.p + kRbTotals), *tot = st + 4, *sum = st + 8;
+  memcpy (e->cache.raw (), rbh + kRbCache, kIcaoSlots * sizeof (uint32_t));
+  const unsigned long long *st = reinterpret_cast<const unsigned long long *> (rbh + kRbTotals), *tot = st + 4, *sum = st + 8;
   if (st[2]) return fail (MODES_E_OVERFLOW, "%llu strips overflowed their candidate slots (cap %u)", st[2], e->cap);
   if (st[3]) return fail (kRetryMagnitudeTile, "the halo holds magnitudes the byte table does not produce");
   e->stats.candidates += st[0];
@@ -752,14 +777,17 @@ int accept_range (modes_engine *e, const ScanParams &sp, uint64_t first_sample, 
   if (nm) {
     if (base + nm > e->d_messages.cap || base + nm > e->pin_cap) {
       // the list outgrew what the run set out with: wait for the read-backs in flight, then move to larger buffers
-      if (base) HIP_TRY (hipStreamSynchronize (copy_stream ? copy_stream : stream));
+      if (base) {
+        if (copy_stream) HIP_TRY (hipStreamSynchronize (e->emit_stream));
+        HIP_TRY (hipStreamSynchronize (copy_stream ? copy_stream : stream));
+      }
       const uint32_t nb_all = ap.nblocks, nb_done = rg.blk0 + rg.nblk;
       const size_t guess = size_t (double (base + nm) * double (nb_all) / double (nb_done) * 1.25) + 1024;
       if ((rc = reserve_messages (e, guess, base)) != MODES_OK) return rc;
     }
     EmitParams ep;
     memset (&ep, 0, sizeof ep);
-    ep.records = e->records.p; ep.counts = e->counts.p; ep.acc_counts = e->acc_counts.p; ep.offsets = e->offsets.p;
+    ep.records = e->records.p; ep.counts = e->counts.p; ep.acc_counts = e->acc_counts.p; ep.offsets = e->offsets.p + size_t ((rounds - 1) & 1) * sp.nstrips;
     ep.cap = e->cap; ep.nstrips = sp.nstrips;
     ep.iq = sp.iq; ep.nsamples = sp.nsamples; ep.navail = sp.navail; ep.halo = sp.halo; ep.ov = sp.ov;
     ep.block_samples = sp.block_samples; ep.conv = sp.conv; ep.lut256 = sp.lut256;
@@ -767,21 +795,24 @@ int accept_range (modes_engine *e, const ScanParams &sp, uint64_t first_sample, 
     ep.messages = e->d_messages.p + base;             // offsets[] count from the range's first strip
     ep.mode = e->mode;
     ep.strip_begin = rg.strip0; ep.strip_end = rg.strip0 + rg.nstrips;
-    HIP_TRY (launch_strip_offsets (acc_counts, rg.nstrips, e->chunk_sum.p, e->offsets.p + rg.strip0, stream));
-    HIP_TRY (launch_emit2400 (ep, stream));
+    // With streams of their own the emit and the read-back leave the pass's stream as soon as the round that settled
+    // the range has ended (not the round queued behind it): pass, emit and read-back of consecutive ranges form a
+    // pipeline of three stages beside the scan.
     hipStream_t cs = stream;
-    if (copy_stream) {                                // the read-back does not hold up the next range's pass
-      HIP_TRY (hipEventRecord (emitted, stream));
+    if (copy_stream) {
+      HIP_TRY (hipStreamWaitEvent (e->emit_stream, e->round_ev[(rounds - 1) & 1], 0));
+      HIP_TRY (launch_emit2400 (ep, e->emit_stream));
+      HIP_TRY (hipEventRecord (emitted, e->emit_stream));
       HIP_TRY (hipStreamWaitEvent (copy_stream, emitted, 0));
       cs = copy_stream;
-    }
+    } else HIP_TRY (launch_emit2400 (ep, stream));
     HIP_TRY (hipMemcpyAsync (e->pin_msgs + base, e->d_messages.p + base, nm * sizeof (modes_message), hipMemcpyDeviceToHost, cs));
     e->pin_n = base + nm;
   }
   e->in_pinned = true;
   if (last) {
     HIP_TRY (hipStreamSynchronize (stream));
-    if (copy_stream) HIP_TRY (hipStreamSynchronize (copy_stream));
+    if (copy_stream) { HIP_TRY (hipStreamSynchronize (e->emit_stream)); HIP_TRY (hipStreamSynchronize (copy_stream)); }
   }
   return MODES_OK;
 }
@@ -813,6 +844,7 @@ int scan_and_accept_in_ranges (modes_engine *e, ScanParams &sp, uint64_t first_s
   if (rc != MODES_OK) return rc;
   if (!e->post_stream) HIP_TRY (hipStreamCreateWithFlags (&e->post_stream, hipStreamNonBlocking));
   if (!e->copy_stream) HIP_TRY (hipStreamCreateWithFlags (&e->copy_stream, hipStreamNonBlocking));
+  if (!e->emit_stream) HIP_TRY (hipStreamCreateWithFlags (&e->emit_stream, hipStreamNonBlocking));
   while (e->emit_events.size () < size_t (nranges)) {
     hipEvent_t ev;
     HIP_TRY (hipEventCreateWithFlags (&ev, hipEventDisableTiming));
@@ -848,7 +880,10 @@ int scan_and_accept_in_ranges (modes_engine *e, ScanParams &sp, uint64_t first_s
   // on any way out nothing of this run is left in flight on either stream
   struct Drain {
     modes_engine *e; hipStream_t s;
-    ~Drain () { (void) hipStreamSynchronize (e->post_stream); (void) hipStreamSynchronize (e->copy_stream); (void) hipStreamSynchronize (s); }
+    ~Drain () {
+      (void) hipStreamSynchronize (e->post_stream); (void) hipStreamSynchronize (e->emit_stream); (void) hipStreamSynchronize (e->copy_stream);
+      (void) hipStreamSynchronize (s);
+    }
   } drain = { e, stream };
   e->pin_n = 0;
   HIP_TRY (hipMemsetAsync (e->rb.p + kRbInexactWord, 0, 2 * sizeof (uint32_t), stream));
@@ -930,15 +965,17 @@ void modes_engine_destroy (modes_engine *e)
   e->dc_lin.release (); e->dc_ticks.release (); e->dc_zc.release (); e->dc_closed.release ();
   for (hipEvent_t ev : e->dc_ev) if (ev) (void) hipEventDestroy (ev);
   if (e->dc_power_done) (void) hipEventDestroy (e->dc_power_done);
+  for (hipEvent_t ev : e->round_ev) if (ev) (void) hipEventDestroy (ev);
   e->dc_mag.release (); e->dc_sq.release (); e->dc_desc.release (); e->dc_zs.release (); e->dc_ze.release (); e->dc_unm.release ();
   e->d8_trig.release (); e->d8_amb.release (); e->d8_off.release (); e->d8_p0.release (); e->d8_mx.release ();
   e->d8_win_count.release (); e->d8_chunk_rec.release (); e->d8_announce.release (); e->d8_table.release (); e->d8_entry.release ();
   e->d8_win_start.release (); e->d8_small.release (); e->d8_windows.release (); e->d8_win_packed.release ();
-  e->d8_records.release (); e->d8_rec_packed.release (); e->dirty.release (); e->blk_wrote.release (); e->rb.release (); e->pin_rb.release (); e->pin_sums.release (); e->pin_tot.release (); e->d8_tot.release (); e->pin_wins2.release (); e->pin_recs2.release (); e->pin_rpos.release (); e->pin_rlen.release ();
+  e->d8_records.release (); e->d8_rec_packed.release (); e->dirty.release (); e->blk_wrote.release (); e->rb.release (); e->pin_rb.release (); e->pin_entry.release (); e->pin_sums.release (); e->pin_tot.release (); e->d8_tot.release (); e->pin_wins2.release (); e->pin_recs2.release (); e->pin_rpos.release (); e->pin_rlen.release ();
   e->d8_dprev.release (); e->d8_dnext.release (); e->pin_d8.release (); e->d8_exit_of.release ();
   e->d_fields.release (); e->pin_fields.release ();
   if (e->post_stream) (void) hipStreamDestroy (e->post_stream);
   if (e->copy_stream) (void) hipStreamDestroy (e->copy_stream);
+  if (e->emit_stream) (void) hipStreamDestroy (e->emit_stream);
   for (hipEvent_t ev : e->emit_events) if (ev) (void) hipEventDestroy (ev);
   for (hipEvent_t ev : e->range_events) if (ev) (void) hipEventDestroy (ev);
   e->pin_wins.release (); e->pin_recs.release (); e->pin_bits.release ();

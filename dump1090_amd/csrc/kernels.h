@@ -52,10 +52,12 @@ hipError_t launch_dc_block_power (const float *sq, uint64_t n, uint32_t block_sa
 hipError_t launch_dc_linear (int conv, const uint8_t *iq, uint64_t n, double A, double B, double *out, hipStream_t stream);
 hipError_t launch_accept2400 (const AcceptParams &p, hipStream_t stream);
 hipError_t launch_snapshots (const uint32_t *delta, const uint32_t *blk_wrote, uint32_t nblocks, const uint32_t *cache_in, uint32_t *chunk_last,
-                             uint32_t *chunk_entry, uint32_t *snap_in, uint32_t *cache_out, uint32_t *dirty, const uint32_t *changed,
+                             uint32_t *chunk_entry, uint32_t *snap_in, uint32_t *cache_out, uint32_t *dirty, const uint32_t *changed, uint32_t *marked,
                              int first_round, hipStream_t stream);
 hipError_t launch_emit2400 (const EmitParams &p, hipStream_t stream);
 hipError_t launch_strip_offsets (const uint32_t *acc_counts, uint32_t nstrips, const uint64_t *chunk_sum, uint64_t *offsets, hipStream_t stream);
+hipError_t launch_fill_u32 (uint32_t *p, size_t n, uint32_t v, hipStream_t stream);
+hipError_t launch_copy_u32 (uint32_t *dst, const uint32_t *src, size_t n, hipStream_t stream);
 hipError_t launch_blk_stats_sum (const uint32_t *blk_stats, uint32_t nblocks, unsigned long long *out, hipStream_t stream);
 hipError_t launch_count_scan (const uint32_t *counts, const uint32_t *vp_counts, uint32_t nstrips, uint64_t *chunk_sum,
                               uint64_t *chunk_vp, uint64_t *chunk_ovf, uint64_t *totals, hipStream_t stream);

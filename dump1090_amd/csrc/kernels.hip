@@ -1030,20 +1030,22 @@ void accept_kernel (const AcceptParams p)
 constexpr int kSnapChunk = 32;
 
 // The three kernels below run behind every accept round.  `changed` is that round's word: when no delta changed (in the
-// first round: no block wrote anything) the snapshots, the dirty marks and the cache behind the last block are what
-// they were, and the kernels leave at once -- a pass over a shard without accepted squitters costs no snapshot traffic.
+// first round: no block wrote anything) the snapshots and the cache behind the last block are what they were, no block
+// is marked dirty, and the kernels leave at once -- a pass over a shard without accepted squitters costs no snapshot traffic.
 
 // last write per (chunk of blocks, slot)
 __global__ __launch_bounds__ (256)
 void snap_chunk_last_kernel (const uint32_t *delta, const uint32_t *blk_wrote, uint32_t nblocks, uint32_t *chunk_last, uint32_t *dirty,
                              const uint32_t *changed)
 {
-  if (!*changed) return;
   const uint32_t s = blockIdx.x * 256 + threadIdx.x, chunk = blockIdx.y;
   if (s >= kIcaoSlots) return;
   uint32_t v = 0;
   const uint32_t b0 = chunk * kSnapChunk, b1 = min (b0 + kSnapChunk, nblocks);
-  if (s < kSnapChunk && b0 + s < b1) dirty[b0 + s] = 0u;             // snap_fill_kernel, next in the stream, marks the blocks to repeat
+  // snap_fill_kernel, next in the stream, marks the blocks to repeat.  The marks are cleared after a round without a
+  // change as well: the engine queues one round beyond the last, and that round must not touch a block.
+  if (s < kSnapChunk && b0 + s < b1) dirty[b0 + s] = 0u;
+  if (!*changed) return;
   for (uint32_t b = b0; b < b1; b++) {
     if (!blk_wrote[b]) continue;
     const uint32_t d = delta[size_t (b) * kIcaoSlots + s];
@@ -1082,7 +1084,7 @@ void snap_chunk_scan_kernel (const uint32_t *chunk_last, uint32_t nchunks, const
 
 __global__ __launch_bounds__ (256)
 void snap_fill_kernel (const uint32_t *delta, const uint32_t *blk_wrote, uint32_t nblocks, const uint32_t *chunk_entry, uint32_t *snap_in,
-                       uint32_t *dirty, const uint32_t *changed, const uint32_t *cache_in, int first_round)
+                       uint32_t *dirty, const uint32_t *changed, const uint32_t *cache_in, int first_round, uint32_t *marked)
 {
   if (!*changed) return;
   const uint32_t s = blockIdx.x * 256 + threadIdx.x, chunk = blockIdx.y;
@@ -1090,16 +1092,20 @@ void snap_fill_kernel (const uint32_t *delta, const uint32_t *blk_wrote, uint32_
   uint32_t cur = chunk_entry[size_t (chunk) * kIcaoSlots + s];
   const uint32_t first = cache_in[s];                              // what every block started from in the first round
   const uint32_t b0 = chunk * kSnapChunk, b1 = min (b0 + kSnapChunk, nblocks);
+  bool any = false;
   for (uint32_t b = b0; b < b1; b++) {
     // a block whose entry cache is what it was in the round before would repeat itself: only the others run again
     uint32_t *sn = snap_in + size_t (b) * kIcaoSlots + s;
-    if (first_round) { *sn = cur; if (cur != first) dirty[b] = 1u; }
-    else if (*sn != cur) { *sn = cur; dirty[b] = 1u; }
+    if (first_round) { *sn = cur; if (cur != first) { dirty[b] = 1u; any = true; } }
+    else if (*sn != cur) { *sn = cur; dirty[b] = 1u; any = true; }
     if (blk_wrote[b]) {
       const uint32_t d = delta[size_t (b) * kIcaoSlots + s];
       if (d & kDeltaWritten) cur = d & ~kDeltaWritten;
     }
   }
+  // Deltas can change without any block's entry cache changing (a slot written again with what it held): then no block
+  // is marked, the round just run was already the last one, and `marked` stays clear to say so.
+  if (__ballot (any) && (threadIdx.x & 63) == 0) atomicOr (marked, 1u);
 }
 
 // sums of the per-block statistics: out[k] = sum over blocks of blk_stats[block][k]
@@ -1414,6 +1420,36 @@ hipError_t upload_constants (const uint32_t *single_bit, const float *uc8_float)
   return upload_constants_8000 (single_bit, uc8_float);
 }
 
+// Small fills and copies as kernels: a hipMemsetAsync / hipMemcpyAsync on the stream of the ordered pass is a blit that
+// queues behind the read-back of the range before (tens of MB on the copy stream) and held the pass up for as long as
+// that copy lasted.  `dst` or `src` of the copy may be pinned host memory (a few KB over PCIe).
+__global__ __launch_bounds__ (256)
+void fill_u32_kernel (uint32_t *p, size_t n, uint32_t v)
+{
+  const size_t stride = size_t (gridDim.x) * blockDim.x;
+  for (size_t i = size_t (blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+__global__ __launch_bounds__ (256)
+void copy_u32_kernel (uint32_t *dst, const uint32_t *src, size_t n)
+{
+  const size_t stride = size_t (gridDim.x) * blockDim.x;
+  for (size_t i = size_t (blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+hipError_t launch_fill_u32 (uint32_t *p, size_t n, uint32_t v, hipStream_t stream)
+{
+  if (!n) return hipSuccess;
+  const size_t want = (n + 255) / 256;
+  hipLaunchKernelGGL (fill_u32_kernel, dim3 ((unsigned) (want < 1024 ? want : 1024)), dim3 (256), 0, stream, p, n, v);
+  return hipGetLastError ();
+}
+hipError_t launch_copy_u32 (uint32_t *dst, const uint32_t *src, size_t n, hipStream_t stream)
+{
+  if (!n) return hipSuccess;
+  const size_t want = (n + 255) / 256;
+  hipLaunchKernelGGL (copy_u32_kernel, dim3 ((unsigned) (want < 256 ? want : 256)), dim3 (256), 0, stream, dst, src, n);
+  return hipGetLastError ();
+}
+
 hipError_t launch_scan2400 (const ScanParams &p, hipStream_t stream)
 {
   const dim3 block (64 * kWavesPerBlock);
@@ -1553,13 +1589,13 @@ hipError_t launch_accept2400 (const AcceptParams &p, hipStream_t stream)
 // delta -> snap_in for the next round; chunk_last/chunk_entry hold (nblocks/32 + 1) * 1024 words each
 hipError_t launch_snapshots (const uint32_t *delta, const uint32_t *blk_wrote, uint32_t nblocks, const uint32_t *cache_in, uint32_t *chunk_last,
                              uint32_t *chunk_entry, uint32_t *snap_in, uint32_t *cache_out, uint32_t *dirty, const uint32_t *changed,
-                             int first_round, hipStream_t stream)
+                             uint32_t *marked, int first_round, hipStream_t stream)
 {
   if (nblocks == 0) return hipSuccess;
   const uint32_t nchunks = (nblocks + kSnapChunk - 1) / kSnapChunk;
   hipLaunchKernelGGL (snap_chunk_last_kernel, dim3 (kIcaoSlots / 256, nchunks), dim3 (256), 0, stream, delta, blk_wrote, nblocks, chunk_last, dirty, changed);
   hipLaunchKernelGGL (snap_chunk_scan_kernel, dim3 (kIcaoSlots / 256), dim3 (256), 0, stream, chunk_last, nchunks, cache_in, chunk_entry, cache_out, changed, first_round);
-  hipLaunchKernelGGL (snap_fill_kernel, dim3 (kIcaoSlots / 256, nchunks), dim3 (256), 0, stream, delta, blk_wrote, nblocks, chunk_entry, snap_in, dirty, changed, cache_in, first_round);
+  hipLaunchKernelGGL (snap_fill_kernel, dim3 (kIcaoSlots / 256, nchunks), dim3 (256), 0, stream, delta, blk_wrote, nblocks, chunk_entry, snap_in, dirty, changed, cache_in, first_round, marked);
   return hipGetLastError ();
 }
 
