@@ -205,6 +205,8 @@ def run_workload(name, args, world, rank, local, dev, want_cpu):
             recs.append((iq, info))
     torch.cuda.synchronize()
     gen_s = time.time() - t0
+    if os.environ.get("MODES_BENCH_PROGRESS"):
+        print("[rank %d] %s: input formed in %.1f s" % (rank, name, gen_s), file=sys.stderr, flush=True)
     nbytes = recs[0][0].numel() * recs[0][0].element_size() - lead * bps
     eng = da.Engine(rate, fmt_id, device=local, **dict(ekw, compute_power=power))
     stream = torch.cuda.current_stream().cuda_stream
@@ -267,6 +269,8 @@ def run_workload(name, args, world, rank, local, dev, want_cpu):
     for _ in range(args.warmup):
         one_step()
     barrier()
+    if os.environ.get("MODES_BENCH_PROGRESS"):
+        print("[rank %d] %s: warm-up done" % (rank, name), file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     kms = k2 = 0.0
     nm = 0
@@ -462,6 +466,9 @@ def main():
     ap.add_argument("--traffic", type=float, default=None, help="HBM bytes per launch of the roofline kernel from PMC counters")
     args = ap.parse_args()
 
+    if os.environ.get("MODES_BENCH_WATCHDOG"):       # seconds: where every thread stands, should the run take that long
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["MODES_BENCH_WATCHDOG"]), exit=False, file=sys.stderr)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

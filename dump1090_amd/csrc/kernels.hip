@@ -137,7 +137,8 @@ void scan2400_kernel (const ScanParams p)
   if constexpr (kRaw) {
     const long long a0 = s0 - kRawShift2400;        // G0 and the launch's first strip are multiples of 16, ov = kOv2400
     if (!(a0 >= 0 && a0 + kRawBytes <= (long long) p.nsamples)) __syncthreads ();     // workgroup-uniform: the slow path reads s_lut
-    stage_tile_raw<kRawBytes, kWavesPerBlock> (s_tile, s_lut, p, a0, wv, lane, int (threadIdx.x));
+    if (p.debug_stop != 9)                            // (9: the stage probe's run without loads, on whatever tile the LDS holds)
+      stage_tile_raw<kRawBytes, kWavesPerBlock> (s_tile, s_lut, p, a0, wv, lane, int (threadIdx.x));
     asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");       // the DMA writes land before the barrier lets anyone read
   } else if constexpr (kR8) {
     stage_tile_rank8<kStageHalf, 64 * kWavesPerBlock> (s_tile + kLead, s_rank, s_lut, p, s0, int (threadIdx.x));

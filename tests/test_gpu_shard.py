@@ -139,7 +139,7 @@ def _run_ranks(world, make_shard):
 
 
 @pytest.mark.parametrize("rate,fmt,world", [(2400000, "sc16", 3), (2000000, "sc16", 2), (2400000, "uc8lut", 2), (8000000, "sc16", 3),
-                                            (8000000, "quiet", 3), (8000000, "noisy", 4)])
+                                            (8000000, "quiet", 3), (8000000, "noisy", 4), (2400000, "sc16", 8), (8000000, "sc16", 8)])
 def test_engine_shards_reach_the_single_pass_result(rate, fmt, world):
     """The product path of a sharded decode: every rank holds only its shard and one block in front of it, forms its
     own halo, and the entry states (ICAO cache; at 8 MS/s also demod_8000's carried state) are handed over until they
@@ -150,13 +150,16 @@ def test_engine_shards_reach_the_single_pass_result(rate, fmt, world):
         iq, _ = synth.capture(65536 * 11 + 777, 8e6, "sc16", seed=97, frames_per_sec=1500, ap_fraction=0.3, n_icao=6)
         efmt, bps, ofmt = da.INPUT_SC16, 4, "sc16"
     elif rate == 8000000:
-        iq = _capture_8000(nblocks=9, quiet=fmt == "quiet")
+        iq = _capture_8000(nblocks=9 if world < 8 else 25, quiet=fmt == "quiet")
         efmt, bps, ofmt = da.INPUT_SC16, 4, "sc16"
     elif fmt == "uc8lut":
         iq, _ = synth.capture_lut_image(131072 * 7 + 999, 2.4e6, seed=96, frames_per_sec=3000, min_amp_db=-22, ap_fraction=0.5, n_icao=6)
         efmt, bps, ofmt = da.INPUT_UC8, 2, "uc8"
     else:
-        iq, _ = synth.capture(65536 * 9 + 4321, float(rate), "sc16", seed=92, frames_per_sec=2500, ap_fraction=0.5, n_icao=6, bitflip1=0.2)
+        # (eight shards: the node's worth of ranks, three blocks each, and an aircraft population that does not fit
+        # the first shard -- caches keep changing down the chain of shards)
+        iq, _ = synth.capture(65536 * (9 if world < 8 else 25) + 4321, float(rate), "sc16", seed=92, frames_per_sec=2500, ap_fraction=0.5,
+                              n_icao=6 if world < 8 else 64, bitflip1=0.2)
         efmt, bps, ofmt = da.INPUT_SC16, 4, "sc16"
     exp, _ = oracle_run(iq, ofmt, rate=rate)
     B = 262144 // bps
@@ -175,7 +178,9 @@ def test_engine_shards_reach_the_single_pass_result(rate, fmt, world):
     assert_same_messages(got, exp)
     assert len(exp) > 40
     rounds = res[0][1]
-    assert 2 <= rounds <= (world + 1 if fmt != "quiet" else 2 * world + 2)
+    assert 2 <= rounds <= (min(world + 1, 4) if fmt != "quiet" else 2 * world + 2)
+    if world >= 8 and rate != 8000000:
+        assert len(np.unique(exp["addr"][np.isin(exp["msg_type"], (11, 17))])) >= 50
     assert len(exp) > (100 if fmt == "noisy" else 40)
     for r, (_, _, sh) in enumerate(res):
         c = sh.e.counters()
