@@ -2,7 +2,7 @@
 # Runs on the GPU box (gpurun): for every bench workload one rocprofv3 --kernel-trace --stats run of bench.py (kernel
 # stats CSV and the JSON line of THAT run are kept as a pair, or not at all), then FETCH_SIZE and WRITE_SIZE passes
 # (separate --pmc runs, no tracing options) for the HBM traffic of the dominant kernel.
-# Results land in gpurun_out/profiles_raw/; tools/summarise_profiles.py turns them into profiles/r02_*.
+# Results land in gpurun_out/profiles_raw/; tools/summarise_profiles.py turns them into profiles/r03_*.
 #   usage: tools/collect_profiles.sh [stats|pmc|all] [workload ...]
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 what=${1:-all}; shift

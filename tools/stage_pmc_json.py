@@ -1,4 +1,4 @@
-"""gpurun_out/pmc_<fmt>_<pass> (tools/stage_pmc.sh) -> profiles/r02_pmc_scan_stages.json: per-strip counters of the scan
+"""gpurun_out/pmc_<fmt>_<pass> (tools/stage_pmc.sh) -> profiles/r03_pmc_scan_stages.json: per-strip counters of the scan
 kernel stopped after each stage."""
 import collections
 import csv
@@ -41,6 +41,6 @@ out["note"] = ("rocprofv3 --pmc, two passes (SQ_INSTS_VALU SQ_INSTS_SALU SQ_INST
                "2048-position strip (the byte-table instances scan two strips per wave).  A wave64 VALU instruction occupies its SIMD "
                "for 4 cycles: INSTS_VALU x 4 x strips per SIMD is the kernel's floor in cycles.  valu_lanes_busy_frac = "
                "THREAD_CYCLES_VALU / (64 x ACTIVE_INST_VALU).")
-json.dump(out, open('profiles/r02_pmc_scan_stages.json', 'w'), indent=1)
+json.dump(out, open('profiles/r03_pmc_scan_stages.json', 'w'), indent=1)
 for tag in ("sc16", "uc8"):
     print(tag, {k: (v.get("INSTS_VALU"), v.get("valu_lanes_busy_frac")) for k, v in out[tag]["per_strip"].items()}, out[tag]["ms_under_profiler_1GiB"])

@@ -7,7 +7,8 @@ n = (1<<30)//(2 if fmt=='uc8' else 4)
 iq, info = synth_torch.capture_gpu(n, 2.4e6, fmt, seed=1, device='cuda:0')
 e = da.Engine(2400000, da.INPUT_UC8 if fmt=='uc8' else da.INPUT_SC16)
 nb = iq.numel()*iq.element_size()
-for stop in (1,2,3,0) + ((9,) if fmt == 'uc8' else ()):       # 9: everything but the loads (raw-byte tile)
+noload = len(sys.argv) > 2 and sys.argv[2] == 'noload'        # one more run: everything but the loads (uc8's raw-byte tile)
+for stop in (1,2,3,0) + ((9,) if noload and fmt == 'uc8' else ()):
     os.environ['MODES_DEBUG_STOP'] = str(stop)
     e.time_scan(iq.data_ptr(), nb, reps=2)
     ms = e.time_scan(iq.data_ptr(), nb, reps=5)

@@ -1,4 +1,4 @@
-"""gpurun_out/profiles_raw (tools/collect_profiles.sh) -> profiles/r02_*: kernel stats of this library's kernels per
+"""gpurun_out/profiles_raw (tools/collect_profiles.sh) -> profiles/<round>_*: kernel stats of this library's kernels per
 workload with the bench line of the same run, and the dominant kernel's HBM traffic per step from FETCH_SIZE / WRITE_SIZE
 (separate passes).  Fails when a workload's kernel-stats CSV and its bench line disagree by more than 10 % on the
 dominant kernel's time per step: then they are not from one run (or the live HIP-event timing is off)."""
@@ -9,7 +9,8 @@ import json
 import os
 import sys
 
-raw, out, tag = "gpurun_out/profiles_raw", "profiles", "r02"
+raw, out = "gpurun_out/profiles_raw", "profiles"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"                    # the round the files are named after
 RUNS = 4                                                  # bench.py --steps 3 --warmup 1
 os.makedirs(out, exist_ok=True)
 bad = []
@@ -22,7 +23,8 @@ for d in sorted(glob.glob(raw + "/stats_*")):
     keep = [rows[0]] + [r for r in rows[1:] if "modes::" in r[0]]
     b = json.load(open("%s/bench_%s.json" % (raw, wl)))
     kern = b["roofline"]["kernel"]
-    total_ns = sum(float(r[2]) for r in keep[1:] if kern in r[0])
+    kerns = kern.split(" + ")                              # (8 MS/s: the trigger and the window kernel together)
+    total_ns = sum(float(r[2]) for r in keep[1:] if any(k in r[0] for k in kerns))
     alone = b["roofline"].get("kernel_ms_alone")
     if isinstance(alone, float):                          # bench.py: one more launch of the kernel, alone, behind the timed steps
         total_ns -= alone * 1e6
@@ -52,6 +54,7 @@ for f in sorted(glob.glob(raw + "/FETCH_SIZE_*.json")):
     except (ValueError, IndexError):
         continue
     kern = b["roofline"]["kernel"]
+    kerns = kern.split(" + ")
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         files = glob.glob("%s/%s_%s/*/*counter_collection.csv" % (raw, ctr, wl))
         if len(files) != 1:
@@ -68,12 +71,12 @@ for f in sorted(glob.glob(raw + "/FETCH_SIZE_*.json")):
         for k in res[ctr + "_KB_per_step"]:
             if extra:                                     # every kernel of the decode ran once more
                 res[ctr + "_KB_per_step"][k] = round(res[ctr + "_KB_per_step"][k] * RUNS / (RUNS + extra), 1)
-                if kern in k:
+                if any(q in k for q in kerns):
                     res[ctr + "_launches_per_step"][k] = round((res[ctr + "_launches_per_step"][k] * RUNS - extra) / RUNS, 2)
                 else:
                     res[ctr + "_launches_per_step"][k] = round(res[ctr + "_launches_per_step"][k] * RUNS / (RUNS + extra), 2)
-    fetch = sum(v for k, v in res["FETCH_SIZE_KB_per_step"].items() if kern in k)
-    write = sum(v for k, v in res["WRITE_SIZE_KB_per_step"].items() if kern in k)
+    fetch = sum(v for k, v in res["FETCH_SIZE_KB_per_step"].items() if any(q in k for q in kerns))
+    write = sum(v for k, v in res["WRITE_SIZE_KB_per_step"].items() if any(q in k for q in kerns))
     res["kernel"] = kern
     res["traffic_bytes_per_step"] = int((2 * fetch + write) * 1024)
     res["all_kernels_traffic_bytes_per_step"] = int((2 * sum(res["FETCH_SIZE_KB_per_step"].values()) + sum(res["WRITE_SIZE_KB_per_step"].values())) * 1024)
