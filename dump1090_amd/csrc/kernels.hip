@@ -117,10 +117,18 @@ void scan2400_kernel (const ScanParams p)
   const int lane = lane_id ();
   const int wv = __builtin_amdgcn_readfirstlane (int (threadIdx.x >> 6));    // wave-uniform: what derives from it is scalar arithmetic
   WaveLds<PE, kPair> &w = lds[wv];
+  // The tables are fetched first and stored last: the raw tile's DMA is issued between the two, so the wait for the
+  // tables does not stand in front of it (its staging reads them only on its slow path, behind a barrier of its own).
+  uint16_t lut_mine = 0;
+  uint8_t rank_mine = 0;
   if (kLut) {
-    s_lut[threadIdx.x] = (kR8 && !kRaw) ? p.rankmag[threadIdx.x] : p.lut256[threadIdx.x];
-    if (kR8) s_rank[threadIdx.x] = p.rank256[threadIdx.x];
-    if (!kRaw) __syncthreads ();                  // (the raw tile's staging reads the tables only on its slow path, behind a barrier of its own)
+    lut_mine = (kR8 && !kRaw) ? p.rankmag[threadIdx.x] : p.lut256[threadIdx.x];
+    if (kR8) rank_mine = p.rank256[threadIdx.x];
+    if (!kRaw) {
+      s_lut[threadIdx.x] = lut_mine;
+      if (kR8) s_rank[threadIdx.x] = rank_mine;
+      __syncthreads ();
+    }
   }
   const uint32_t strip = p.strip_begin + (blockIdx.x * kWavesPerBlock + wv) * kPair;   // first strip of this wave's span
   const uint32_t strip_end = p.strip_end ? p.strip_end : p.nstrips;
@@ -136,9 +144,11 @@ void scan2400_kernel (const ScanParams p)
   const long long s0 = G0 - (long long) (CONV == kConvMagU16 ? 0u : p.ov);   // sample index of V[G0] (may be < 0)
   if constexpr (kRaw) {
     const long long a0 = s0 - kRawShift2400;        // G0 and the launch's first strip are multiples of 16, ov = kOv2400
-    if (!(a0 >= 0 && a0 + kRawBytes <= (long long) p.nsamples)) __syncthreads ();     // workgroup-uniform: the slow path reads s_lut
+    const bool interior = a0 >= 0 && a0 + kRawBytes <= (long long) p.nsamples;     // workgroup-uniform
+    if (!interior) { s_lut[threadIdx.x] = lut_mine; s_rank[threadIdx.x] = rank_mine; __syncthreads (); }    // the slow path reads s_lut
     if (p.debug_stop != 9)                            // (9: the stage probe's run without loads, on whatever tile the LDS holds)
       stage_tile_raw<kRawBytes, kWavesPerBlock> (s_tile, s_lut, p, a0, wv, lane, int (threadIdx.x));
+    if (interior) { s_lut[threadIdx.x] = lut_mine; s_rank[threadIdx.x] = rank_mine; }
     asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");       // the DMA writes land before the barrier lets anyone read
   } else if constexpr (kR8) {
     stage_tile_rank8<kStageHalf, 64 * kWavesPerBlock> (s_tile + kLead, s_rank, s_lut, p, s0, int (threadIdx.x));
