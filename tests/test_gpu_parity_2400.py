@@ -106,6 +106,27 @@ def test_uc8_lut_image_messages_match_oracle(compute_power):
     assert_power_stats(engine_run.last, est, noise=compute_power)
 
 
+@pytest.mark.parametrize("shift,variant", [(0, None), (1, None), (8, None), (0, "MODES_RANK_TILE_GATHER"), (0, "MODES_NO_RANK_TILE")])
+def test_uc8_lut_image_at_any_address_and_with_every_tile(shift, variant, monkeypatch):
+    """The byte-table scan fills its tile by LDS DMA when the input allows it (16-byte aligned) and through registers
+    (rank tile, magnitude tile) when it does not: same messages, same statistics, wherever the buffer lies."""
+    import torch
+    iq, _ = synth.capture_lut_image(131072 * 5 + 3333, 2.4e6, seed=43, frames_per_sec=4000, min_amp_db=-22, bitflip1=0.2, ap_fraction=0.2)
+    exp, est = oracle_run(iq, "uc8", fix_bits=1)
+    assert len(exp) > 500
+    if variant:
+        monkeypatch.setenv(variant, "1")
+    buf = torch.zeros(iq.size + 64, dtype=torch.uint8, device="cuda:0")
+    buf[shift: shift + iq.size] = torch.from_numpy(iq).to("cuda:0")
+    assert buf.data_ptr() % 16 == 0
+    e = da.Engine(2400000, da.INPUT_UC8, fix_bits=1)
+    e.run_device(buf.data_ptr() + shift, iq.size)
+    assert_same_messages(e.messages(), exp)
+    gst = e.stats()
+    for k in ("valid_preamble", "demodulated", "CRC_good", "CRC_bad", "CRC_single_bit_fix", "out_of_phase", "demod_rejected_unknown"):
+        assert gst[k] == est[k], k
+
+
 def test_uc8_lut_image_frames_on_block_seams():
     """Frames placed around every 131072-sample block edge of the as-written uc8 converter's output."""
     rng = np.random.default_rng(43)
