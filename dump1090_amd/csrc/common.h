@@ -250,6 +250,7 @@ struct EmitParams {
   uint64_t        first_sample; uint32_t sample_rate;
   void           *messages;      // modes_message[total]
   int32_t         mode;          // 2400 or 2000
+  uint32_t        block_shift;   // log2 (block_samples): set by launch_emit2400, which refuses other block sizes
 };
 
 }  // namespace modes

@@ -512,11 +512,12 @@ __device__ __forceinline__ void glds16 (const uint8_t *src, uint8_t *lds_wave_ba
 }
 
 // byte the as-written converter reads for sample n (ref: src/convert.c:19,29): byte n % B of block n / B
-__device__ __forceinline__ const uint8_t *lut_byte_addr (const ScanParams &p, long long n)
+__device__ __forceinline__ const uint8_t *lut_byte_addr_of (const uint8_t *iq, uint32_t block_samples, long long n)
 {
-  const uint64_t in_blk = uint64_t (n) & uint64_t (p.block_samples - 1);     // block_samples is a power of two
-  return p.iq + 2 * (uint64_t (n) - in_blk) + in_blk;
+  const uint64_t in_blk = uint64_t (n) & uint64_t (block_samples - 1);       // block_samples is a power of two
+  return iq + 2 * (uint64_t (n) - in_blk) + in_blk;
 }
+__device__ __forceinline__ const uint8_t *lut_byte_addr (const ScanParams &p, long long n) { return lut_byte_addr_of (p.iq, p.block_samples, n); }
 
 // a byte whose table value is the magnitude m (the halo in front of a shard): exact only if m is one of the table's values
 __device__ __forceinline__ uint32_t byte_of_mag (const uint16_t *lut, uint32_t m, const ScanParams &p)

@@ -1204,14 +1204,22 @@ template <int CONV>
 __global__ __launch_bounds__ (256)
 void emit2400_kernel (const EmitParams p)
 {
-  // a wave looks at kEmitStrips strips at once: most hold no accepted message
+  // A wave looks at kEmitStrips strips at once (most hold no accepted message), FOUR at a time: a message's signal
+  // level is a sum over at most 268 samples, and what a message costs is the latency of fetching its record and then
+  // its samples, so each 16-lane row of the wave takes a strip of its own and walks that strip's accepted records --
+  // four chains of dependent loads in flight per wave instead of one.  Everything "uniform" below is uniform per row.
+  constexpr bool kEmitLut = CONV == kConvUc8Lut || CONV == kConvUc8LutPower;
+  __shared__ uint16_t s_lut[kEmitLut ? 256 : 1];          // the byte table: a gather from LDS instead of one more trip to L2 per message
+  if (kEmitLut) { s_lut[threadIdx.x] = p.lut256[threadIdx.x]; __syncthreads (); }
   const uint32_t strip_base = p.strip_begin + (blockIdx.x * 4 + (threadIdx.x >> 6)) * kEmitStrips;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, row = lane >> 4, sub = lane & 15;
   if (strip_base >= p.strip_end) return;
   const uint32_t cnt = (lane < kEmitStrips && strip_base + lane < p.strip_end) ? p.acc_counts[strip_base + lane] : 0u;
-  for (u64 sm = __ballot (cnt != 0); sm; sm &= sm - 1) {
-  const uint32_t strip = strip_base + uint32_t (__builtin_ctzll (sm));
-  const uint32_t nacc = bcast (cnt, __builtin_ctzll (sm));
+  if (__ballot (cnt != 0) == 0) return;
+  for (int si = row; si < kEmitStrips; si += 4) {
+  const uint32_t strip = strip_base + uint32_t (si);
+  const uint32_t nacc = uint32_t (__shfl (int (cnt), si, 64));
+  if (nacc == 0) continue;
   MsgOut *out = reinterpret_cast<MsgOut *> (p.messages) + p.offsets[strip];
   const Record *recs = p.records + size_t (strip) * p.cap;
   const uint32_t nrec = p.counts[strip];
@@ -1227,7 +1235,8 @@ void emit2400_kernel (const EmitParams p)
     const uint64_t P = uint64_t (strip) * kStrip + off;
     const int mbits = msg_bits_for_df (int (df));
     const int slen = mbits * 12 / 5;
-    const uint64_t blk = P / p.block_samples, j = P % p.block_samples;
+    // (a block is 256 KiB of input: a power of two samples, so no 64-bit divisions per message)
+    const uint64_t blk = P >> p.block_shift, j = P & uint64_t (p.block_samples - 1);
     const uint64_t counter = p.first_sample + blk * p.block_samples;
     const uint64_t block_ts = uint64_t ((double (counter) * 12E6) / double (p.sample_rate));        // ref: src/infile.c:143
     uint64_t ts = p.mode == 2000 ? block_ts + j * 6                                                  // ref: src/demod-2000.c:960
@@ -1263,7 +1272,7 @@ void emit2400_kernel (const EmitParams p)
     uint4 o0, o1, o2; uint2 o3;
     o0.x = uint32_t (ts); o0.y = uint32_t (ts >> 32); o0.z = uint32_t (mlo); o0.w = uint32_t (mlo >> 32);
     o1.x = uint32_t (mhi); o1.y = (uint32_t (mhi >> 32) & 0xFFFFu) | (msg_bits << 16) | (msg_type << 24); o1.z = addr; o1.w = ocrc;
-    o2.x = uint32_t (uint16_t (oscore)) | (eb << 16) | (oph << 24); o2.y = uint32_t (p.first_sample / p.block_samples + blk);
+    o2.x = uint32_t (uint16_t (oscore)) | (eb << 16) | (oph << 24); o2.y = uint32_t ((p.first_sample >> p.block_shift) + blk);
     o2.z = uint32_t (sigbits); o2.w = uint32_t (sigbits >> 32);
     o3.x = uint32_t (j); o3.y = 0;
     uint32_t *dst = reinterpret_cast<uint32_t *> (out + slot);
@@ -1276,70 +1285,96 @@ void emit2400_kernel (const EmitParams p)
     *reinterpret_cast<uint2 *> (dst + 12) = o3;
   };
   uint32_t k = 0;
-  for (uint32_t rb = 0; rb < nrec && k < nacc; rb += 64) {
+  for (uint32_t rb = 0; rb < nrec && k < nacc; rb += 16) {
     uint4 ra = { 0, 0, 0, 0 }, rc = { 0, 0, 0, 0 };
-    if (rb + lane < nrec) { const uint4 *s4 = reinterpret_cast<const uint4 *> (recs + rb + lane); ra = s4[0]; rc = s4[1]; }
+    if (rb + sub < nrec) { const uint4 *s4 = reinterpret_cast<const uint4 *> (recs + rb + sub); ra = s4[0]; rc = s4[1]; }
+    const bool mine = (rc.z >> 16) & 1u;                                                  // flags bit 0: accepted
+    uint32_t accm = uint32_t (__ballot (mine) >> (16 * row)) & 0xFFFFu;                    // the row's own records
     if (p.mode == 2000) {
       // demod_2000's messages carry no measured level (decode_mode_S_message's memset wipes it): nothing is summed, so
       // every accepted record of the batch becomes its message in its own lane
-      const bool mine = (rc.z >> 16) & 1u;
-      const u64 accm = __ballot (mine);
-      if (mine) build (ra.x, ra.y, ra.z, ra.w, rc.x, rc.y, rc.z, rc.w, 0, k + uint32_t (__popcll (accm & ((1ull << lane) - 1))));
-      k += uint32_t (__popcll (accm));
+      if (mine) build (ra.x, ra.y, ra.z, ra.w, rc.x, rc.y, rc.z, rc.w, 0, k + uint32_t (__popc (accm & ((1u << sub) - 1u))));
+      k += uint32_t (__popc (accm));
       continue;
     }
-    for (u64 accm = __ballot ((rc.z >> 16) & 1u); accm; accm &= accm - 1, k++) {        // flags bit 0
-      const int src = __builtin_ctzll (accm);
-      const uint32_t d0 = bcast (ra.x, src), d1 = bcast (ra.y, src), crc = bcast (ra.z, src), d3 = bcast (ra.w, src);
-      const uint32_t d4 = bcast (rc.x, src), d5 = bcast (rc.y, src), d6 = bcast (rc.z, src), d7 = bcast (rc.w, src);
+    for (; accm; accm &= accm - 1, k++) {
+      const int src = 16 * row + __builtin_ctz (accm);
+      const uint32_t d0 = uint32_t (__shfl (int (ra.x), src, 64)), d1 = uint32_t (__shfl (int (ra.y), src, 64)),
+                     crc = uint32_t (__shfl (int (ra.z), src, 64)), d3 = uint32_t (__shfl (int (ra.w), src, 64));
+      const uint32_t d4 = uint32_t (__shfl (int (rc.x), src, 64)), d5 = uint32_t (__shfl (int (rc.y), src, 64)),
+                     d6 = uint32_t (__shfl (int (rc.z), src, 64)), d7 = uint32_t (__shfl (int (rc.w), src, 64));
       const uint32_t off = d0 & 0xFFFF, df = d0 >> 24;
       const uint64_t P = uint64_t (strip) * kStrip + off;
       const int slen = msg_bits_for_df (int (df)) * 12 / 5;
       u64 acc = 0;                                  // ref: src/demod-2400.c:486-497
-      if (p.mode != 2000) {
+      {
+        // a lane takes four neighbouring samples at a time: five wide loads per lane cover the 268 samples of a long message
+        constexpr int NQ = (kLongBits * 12 / 5 + 63) / 64;
         const long long n0 = (long long) P + 19 - (long long) p.ov;                     // first sample of the sum
-        const bool lut = CONV == kConvUc8Lut || CONV == kConvUc8LutPower;
+        const bool lut = kEmitLut;
         if (!lut && CONV != kConvMagU16 && n0 >= 0 && uint64_t (n0) + 320 <= p.nsamples) {
-          // inside the shard: the (at most) five loads of a lane are issued together
-          uint32_t raw[5];
+          // inside the shard: the loads of a lane are issued together (dword-aligned 16-byte / word-aligned 8-byte loads)
+          struct __attribute__ ((packed, aligned (4))) Q4 { uint32_t v[4]; };
+          struct __attribute__ ((packed, aligned (2))) H4 { uint16_t v[4]; };
+          uint32_t raw[NQ][4];
 #pragma unroll
-          for (int q = 0; q < 5; q++) {
-            const int x = lane + 64 * q;
-            if (bps == 2) raw[q] = reinterpret_cast<const uint16_t *> (p.iq)[n0 + x];
-            else          raw[q] = reinterpret_cast<const uint32_t *> (p.iq)[n0 + x];
-          }
+          for (int q = 0; q < NQ; q++) {
+            const int x = 4 * (sub + 16 * q);
 #pragma unroll
-          for (int q = 0; q < 5; q++) {
-            const int x = lane + 64 * q;
-            uint32_t m;
-            if (CONV == kConvUc8Generic) m = mag_from_float (c_uc8_float[raw[q] & 0xFF], c_uc8_float[(raw[q] >> 8) & 0xFF], nullptr);
-            else if (CONV == kConvSc16Int) m = mag_sc16_word (raw[q]) & 0xFFFFu;
-            else {
-              const float sc = CONV == kConvSc16Generic ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
-              m = mag_from_float (float (int16_t (raw[q] & 0xFFFF)) * sc, float (int16_t (raw[q] >> 16)) * sc, nullptr);
+            for (int b = 0; b < 4; b++) raw[q][b] = 0;
+            if (x < slen) {
+              if (bps == 2) { const H4 h = *reinterpret_cast<const H4 *> (reinterpret_cast<const uint16_t *> (p.iq) + n0 + x);
+#pragma unroll
+                              for (int b = 0; b < 4; b++) raw[q][b] = h.v[b]; }
+              else          { const Q4 w = *reinterpret_cast<const Q4 *> (reinterpret_cast<const uint32_t *> (p.iq) + n0 + x);
+#pragma unroll
+                              for (int b = 0; b < 4; b++) raw[q][b] = w.v[b]; }
             }
-            if (x < slen) acc += u64 (m * m);
           }
-        } else if (lut && n0 >= 0 && uint64_t (n0) + 320 <= p.nsamples && uint64_t (n0) % p.block_samples + 320 <= p.block_samples) {
-          // the byte table inside one block: sample i of the block is the table's value for byte i of the block
-          const uint8_t *src = p.iq + uint64_t (n0) / p.block_samples * 2 * p.block_samples + uint64_t (n0) % p.block_samples;
-          uint32_t raw[5];
 #pragma unroll
-          for (int q = 0; q < 5; q++) raw[q] = src[lane + 64 * q];
+          for (int q = 0; q < NQ; q++) {
 #pragma unroll
-          for (int q = 0; q < 5; q++) {
-            const uint32_t m = p.lut256[raw[q]];
-            if (lane + 64 * q < slen) acc += u64 (m * m);
+            for (int b = 0; b < 4; b++) {
+              const int x = 4 * (sub + 16 * q) + b;
+              const uint32_t r = raw[q][b];
+              uint32_t m;
+              if (CONV == kConvUc8Generic) m = mag_from_float (c_uc8_float[r & 0xFF], c_uc8_float[(r >> 8) & 0xFF], nullptr);
+              else if (CONV == kConvSc16Int) m = mag_sc16_word (r) & 0xFFFFu;
+              else {
+                const float sc = CONV == kConvSc16Generic ? (1.0f / 32768.0f) : (1.0f / 2048.0f);
+                m = mag_from_float (float (int16_t (r & 0xFFFF)) * sc, float (int16_t (r >> 16)) * sc, nullptr);
+              }
+              if (x < slen) acc += u64 (m * m);
+            }
+          }
+        } else if (lut && n0 >= 0 && uint64_t (n0) + 320 <= p.nsamples && (uint64_t (n0) & uint64_t (p.block_samples - 1)) + 320 <= p.block_samples
+                   && !(reinterpret_cast<uintptr_t> (p.iq) & 3)) {
+          // the byte table inside one block: sample i of the block is the table's value for byte i of the block.  Whole
+          // dwords from the aligned address at or below the first byte; `sh` bytes of the first one lie in front of the sum
+          const uint8_t *src8 = lut_byte_addr_of (p.iq, p.block_samples, n0);
+          const int sh = int (reinterpret_cast<uintptr_t> (src8) & 3);
+          const uint32_t *src32 = reinterpret_cast<const uint32_t *> (src8 - sh);
+          uint32_t raw[NQ];
+#pragma unroll
+          for (int q = 0; q < NQ; q++) raw[q] = 4 * (sub + 16 * q) < slen + sh ? src32[sub + 16 * q] : 0u;
+#pragma unroll
+          for (int q = 0; q < NQ; q++) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+              const int x = 4 * (sub + 16 * q) + b - sh;
+              const uint32_t m = s_lut[kEmitLut ? (raw[q] >> (8 * b)) & 0xFF : 0u];
+              if (x >= 0 && x < slen) acc += u64 (m * m);
+            }
           }
         } else {
-          for (int q = lane; q < slen; q += 64) {
+          for (int q = sub; q < slen; q += 16) {
             const uint32_t m = mag_of_V<CONV> (p.iq, CONV == kConvMagU16 ? p.navail : p.nsamples, p.halo, p.ov, p.block_samples, p.lut256, (long long) P + 19 + q);
             acc += u64 (m * m);
           }
         }
       }
-      for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor (acc, d, 64);
-      if (lane == 0) build (d0, d1, crc, d3, d4, d5, d6, d7, acc, k);
+      for (int d = 8; d >= 1; d >>= 1) acc += __shfl_xor (acc, d, 64);                   // over the row
+      if (sub == 0) build (d0, d1, crc, d3, d4, d5, d6, d7, acc, k);
     }
   }
   }
@@ -1610,9 +1645,12 @@ hipError_t launch_snapshots (const uint32_t *delta, const uint32_t *blk_wrote, u
   return hipGetLastError ();
 }
 
-hipError_t launch_emit2400 (const EmitParams &p, hipStream_t stream)
+hipError_t launch_emit2400 (const EmitParams &p_in, hipStream_t stream)
 {
-  if (p.strip_end <= p.strip_begin) return hipSuccess;
+  if (p_in.strip_end <= p_in.strip_begin) return hipSuccess;
+  if (p_in.block_samples == 0 || (p_in.block_samples & (p_in.block_samples - 1))) return hipErrorInvalidValue;
+  EmitParams p = p_in;
+  p.block_shift = uint32_t (__builtin_ctz (p.block_samples));
   const uint32_t n = p.strip_end - p.strip_begin;
   const dim3 grid ((n + 4 * kEmitStrips - 1) / (4 * kEmitStrips)), block (256);
   switch (p.conv) {
