@@ -1077,7 +1077,9 @@ static int scan_and_decode (modes_engine *e, ScanParams &sp, uint64_t first_samp
     // fill the wave slots the scan would use, so running them beside the scan gains nothing): three or four ranges
     // for a long shard, none for a short one or when the last run's list was small.
     const uint32_t nblocks = uint32_t ((sp.nsamples + e->block_samples - 1) / e->block_samples);
-    uint32_t nranges = nblocks >= 1024 ? (e->mode == 2000 ? 4u : 3u) : nblocks >= 512 ? 2u : 1u;
+    // (measured, tools/ranges_sweep.sh on 4 GiB: three ranges up to some 0.5 M messages, four above -- the more there is
+    // to emit and read back per range, the more a further range hides)
+    uint32_t nranges = nblocks >= 1024 ? (e->mode == 2000 || (e->have_last_nm && e->last_nm >= 600000) ? 4u : 3u) : nblocks >= 512 ? 2u : 1u;
     if (e->have_last_nm && e->last_nm < 65536) nranges = 1;
     if (const char *ev = getenv ("MODES_RANGES")) { const int v = atoi (ev); if (v >= 1 && v <= 64) nranges = uint32_t (v) < nblocks ? uint32_t (v) : nblocks; }
     if (nranges > 1 && sp.block_strips) {

@@ -1366,6 +1366,25 @@ void emit2400_kernel (const EmitParams p)
               if (x >= 0 && x < slen) acc += u64 (m * m);
             }
           }
+        } else if (CONV == kConvMagU16 && uint64_t (P) + 19 + 320 <= p.navail) {
+          // magnitudes as the DC-block chain left them (the virtual stream V itself): four neighbours per load
+          struct __attribute__ ((packed, aligned (2))) H4 { uint16_t v[4]; };
+          const uint16_t *v16 = reinterpret_cast<const uint16_t *> (p.iq) + P + 19;
+          H4 raw[NQ];
+#pragma unroll
+          for (int q = 0; q < NQ; q++) {
+            const int x = 4 * (sub + 16 * q);
+            if (x < slen) raw[q] = *reinterpret_cast<const H4 *> (v16 + x);
+            else { raw[q].v[0] = raw[q].v[1] = raw[q].v[2] = raw[q].v[3] = 0; }
+          }
+#pragma unroll
+          for (int q = 0; q < NQ; q++) {
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+              const uint32_t m = raw[q].v[b];
+              if (4 * (sub + 16 * q) + b < slen) acc += u64 (m * m);
+            }
+          }
         } else {
           for (int q = sub; q < slen; q += 16) {
             const uint32_t m = mag_of_V<CONV> (p.iq, CONV == kConvMagU16 ? p.navail : p.nsamples, p.halo, p.ov, p.block_samples, p.lut256, (long long) P + 19 + q);
