@@ -46,7 +46,10 @@ void scanac2400_kernel (const ScanParams p)
   __builtin_amdgcn_wave_barrier ();
   const uint16_t *V = w.tile + shift;
 
-  const uint64_t blk = uint64_t (P0) / p.block_samples, jb0 = uint64_t (P0) % p.block_samples;
+  // (the bulk engine's blocks are a power of two samples long: no 64-bit division there; a caller's mag_buf may be any length)
+  const bool pow2 = (p.block_samples & (p.block_samples - 1)) == 0;
+  const uint64_t blk = pow2 ? uint64_t (P0) >> __builtin_ctz (p.block_samples) : uint64_t (P0) / p.block_samples;
+  const uint64_t jb0 = uint64_t (P0) - blk * p.block_samples;
   const uint64_t mlen = min (uint64_t (p.block_samples), p.nsamples - blk * p.block_samples);
   const uint32_t noise_level = p.noise_level[blk];            // ref: :34-35
 
