@@ -860,6 +860,8 @@ int scan_and_accept_in_ranges (modes_engine *e, ScanParams &sp, uint64_t first_s
   // Ranges shrink towards the end (weights R, R-1, .. 1): what is left to do when the last scan ends -- the last
   // range's pass, emit and read-back -- is what the overlap cannot hide.
   const uint64_t wsum = uint64_t (nranges) * (nranges + 1) / 2;
+  // (equal and growing ranges were measured too -- within 0.05 ms of these on the
+  // message-heaviest input, up to 0.5 ms worse elsewhere)
   auto cut = [&] (uint32_t r) -> uint32_t {       // first block of range r
     return uint32_t (uint64_t (nblocks) * (uint64_t (r) * (2 * nranges - r + 1) / 2) / wsum);
   };
@@ -887,15 +889,32 @@ int scan_and_accept_in_ranges (modes_engine *e, ScanParams &sp, uint64_t first_s
   } drain = { e, stream };
   e->pin_n = 0;
   HIP_TRY (hipMemsetAsync (e->rb.p + kRbInexactWord, 0, 2 * sizeof (uint32_t), stream));
-  HIP_TRY (queue_scan (0));
+  // every range's scan is queued at once, back to back on the caller's stream: none waits for the host, which is busy
+  // with the rounds of the ranges before
+  for (uint32_t r = 0; r < nranges; r++) HIP_TRY (queue_scan (r));
+  HIP_TRY (launch_tail (sp, sp.nsamples, e->tail.p + e->tail_half * ((e->ov + 7u) & ~7u), stream));   // what a following shard needs as d_halo
   e->scan_launches++;
+  const bool timing = getenv ("MODES_TIMING") != nullptr;              // the host's way through the ranges on stderr
+  const auto t_start = std::chrono::steady_clock::now ();
+  auto since = [&] { return std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - t_start).count (); };
   for (uint32_t r = 0; r < nranges; r++) {
-    if (r + 1 < nranges) HIP_TRY (queue_scan (r + 1));
-    else HIP_TRY (launch_tail (sp, sp.nsamples, e->tail.p + e->tail_half * ((e->ov + 7u) & ~7u), stream));   // what a following shard needs as d_halo
     HIP_TRY (hipStreamWaitEvent (e->post_stream, e->range_events[2 * r + 1], 0));
+    const uint64_t rounds_before = e->stats.replay_rounds;
+    const double t_in = since ();
     if ((rc = accept_range (e, sp, first_sample, e->post_stream, rgs[r], r + 1 == nranges, e->copy_stream, e->emit_events[r])) != MODES_OK) return rc;
+    if (timing) fprintf (stderr, "  range %u (%u blocks): pass queued at %.3f ms, settled (%llu rounds)%s at %.3f ms, %zu messages so far\n", r, rgs[r].nblk, t_in,
+                         (unsigned long long) (e->stats.replay_rounds - rounds_before), r + 1 == nranges ? " and everything read back" : "", since (), e->pin_n);
   }
   HIP_TRY (hipStreamSynchronize (stream));
+  if (timing) {
+    float t = 0, t0 = 0;
+    for (uint32_t r = 0; r < nranges; r++) {
+      (void) hipEventElapsedTime (&t0, e->range_events[0], e->range_events[2 * r]);
+      (void) hipEventElapsedTime (&t, e->range_events[0], e->range_events[2 * r + 1]);
+      fprintf (stderr, "  scan of range %u: %.3f .. %.3f ms after the first scan began\n", r, t0, t);
+    }
+    fprintf (stderr, "  ranged decode: %.3f ms on the host\n", since ());
+  }
   e->accept_passes++;
   float ms = 0;
   for (uint32_t r = 0; r < nranges; r++) {
