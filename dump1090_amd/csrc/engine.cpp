@@ -187,6 +187,9 @@ struct modes_engine {
   DevBuf<uint32_t> rb;
   PinBuf<uint32_t> pin_rb;             // two landing areas: a round is queued while the one before is read
   hipEvent_t round_ev[2] = { nullptr, nullptr };
+  // MODES_TIMING: device-side marks of a ranged decode (name, event), printed against the first scan's start
+  std::vector<std::pair<std::string, hipEvent_t>> marks;
+  bool marking = false;
   PinBuf<uint32_t> pin_entry;          // the ICAO cache a range is entered with, where a kernel can fetch it
   DevBuf<D8Window> d8_windows, d8_win_packed;
   DevBuf<Record> d8_records, d8_rec_packed;
@@ -655,6 +658,18 @@ int reserve_messages (modes_engine *e, size_t need, size_t keep)
   return MODES_OK;
 }
 
+// a timing mark on `stream` (only while MODES_TIMING is set and a ranged decode is collecting them)
+static void mark (modes_engine *e, hipStream_t stream, const char *fmt, unsigned a = 0, unsigned b = 0)
+{
+  if (!e->marking) return;
+  char name[64];
+  snprintf (name, sizeof name, fmt, a, b);
+  hipEvent_t ev = nullptr;
+  if (hipEventCreate (&ev) != hipSuccess) return;
+  (void) hipEventRecord (ev, stream);
+  e->marks.emplace_back (name, ev);
+}
+
 constexpr uint32_t kRbTotals = 0, kRbChanged = 64, kRbRounds = 64, kRbMarked = kRbChanged + kRbRounds, kRbCache = kRbMarked + kRbRounds, kRbWords = kRbCache + kIcaoSlots;
 
 int reserve_accept_buffers (modes_engine *e, const ScanParams &sp)
@@ -695,6 +710,7 @@ int accept_range (modes_engine *e, const ScanParams &sp, uint64_t first_sample, 
   uint32_t *acc_counts = e->acc_counts.p + rg.strip0, *dirty = e->dirty.p + rg.blk0, *blk_stats = e->blk_stats.p + size_t (rg.blk0) * kBlkStats;
   uint64_t *d_totals = reinterpret_cast<uint64_t *> (e->rb.p + kRbTotals);
 
+  mark (e, stream, "  blocks %u..: pass begins", rg.blk0);
   // totals of the range's scan (candidates, valid preambles, overflowed strips)
   HIP_TRY (launch_count_scan (e->counts.p + rg.strip0, e->vp_counts.p + rg.strip0, rg.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p, d_totals, stream));
   // (kernels, not blits: see launch_fill_u32)
@@ -737,6 +753,7 @@ int accept_range (modes_engine *e, const ScanParams &sp, uint64_t first_sample, 
     HIP_TRY (launch_strip_offsets (acc_counts, rg.nstrips, e->chunk_sum.p, e->offsets.p + size_t (r & 1) * sp.nstrips + rg.strip0, stream));
     HIP_TRY (launch_copy_u32 (e->pin_rb.p + (r & 1) * kRbWords, e->rb.p, kRbWords, stream));          // into pinned host memory
     HIP_TRY (hipEventRecord (e->round_ev[r & 1], stream));
+    mark (e, stream, "  blocks %u..: round %u ends", rg.blk0, r);
     return MODES_OK;
   };
   if (!e->round_ev[0]) for (hipEvent_t &ev : e->round_ev) HIP_TRY (hipEventCreateWithFlags (&ev, hipEventDisableTiming));
@@ -801,12 +818,15 @@ int accept_range (modes_engine *e, const ScanParams &sp, uint64_t first_sample, 
     hipStream_t cs = stream;
     if (copy_stream) {
       HIP_TRY (hipStreamWaitEvent (e->emit_stream, e->round_ev[(rounds - 1) & 1], 0));
+      mark (e, e->emit_stream, "  blocks %u..: emit begins", rg.blk0);
       HIP_TRY (launch_emit2400 (ep, e->emit_stream));
       HIP_TRY (hipEventRecord (emitted, e->emit_stream));
+      mark (e, e->emit_stream, "  blocks %u..: emit ends", rg.blk0);
       HIP_TRY (hipStreamWaitEvent (copy_stream, emitted, 0));
       cs = copy_stream;
     } else HIP_TRY (launch_emit2400 (ep, stream));
     HIP_TRY (hipMemcpyAsync (e->pin_msgs + base, e->d_messages.p + base, nm * sizeof (modes_message), hipMemcpyDeviceToHost, cs));
+    mark (e, cs, "  blocks %u..: read-back ends", rg.blk0);
     e->pin_n = base + nm;
   }
   e->in_pinned = true;
@@ -895,6 +915,7 @@ int scan_and_accept_in_ranges (modes_engine *e, ScanParams &sp, uint64_t first_s
   HIP_TRY (launch_tail (sp, sp.nsamples, e->tail.p + e->tail_half * ((e->ov + 7u) & ~7u), stream));   // what a following shard needs as d_halo
   e->scan_launches++;
   const bool timing = getenv ("MODES_TIMING") != nullptr;              // the host's way through the ranges on stderr
+  e->marking = timing;
   const auto t_start = std::chrono::steady_clock::now ();
   auto since = [&] { return std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - t_start).count (); };
   for (uint32_t r = 0; r < nranges; r++) {
@@ -913,8 +934,16 @@ int scan_and_accept_in_ranges (modes_engine *e, ScanParams &sp, uint64_t first_s
       (void) hipEventElapsedTime (&t, e->range_events[0], e->range_events[2 * r + 1]);
       fprintf (stderr, "  scan of range %u: %.3f .. %.3f ms after the first scan began\n", r, t0, t);
     }
+    for (auto &m : e->marks) {
+      (void) hipEventSynchronize (m.second);
+      (void) hipEventElapsedTime (&t, e->range_events[0], m.second);
+      fprintf (stderr, "%s at %.3f ms\n", m.first.c_str (), t);
+      (void) hipEventDestroy (m.second);
+    }
+    e->marks.clear ();
     fprintf (stderr, "  ranged decode: %.3f ms on the host\n", since ());
   }
+  e->marking = false;
   e->accept_passes++;
   float ms = 0;
   for (uint32_t r = 0; r < nranges; r++) {
