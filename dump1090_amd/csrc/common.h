@@ -204,6 +204,10 @@ struct D8Params {
   uint32_t        nchunks;
   uint32_t        chunk0;        // first chunk of the launch: window / count / gather kernels run on chunk ranges
   uint32_t       *announce;      // [2^24 / 32] addresses that can enter the ICAO cache during the run, or null = no filter
+  // The magnitude plane: d8_trig_kernel, which converts every sample once, leaves V[x] here (x = scan position), and the
+  // window kernel reads its tiles from it instead of converting the samples a second time.  Null = no plane.
+  uint16_t       *vmag;          // [vcap], 16-byte aligned
+  uint64_t        vcap;          // entries allocated, a multiple of 8
 };
 
 // ---- float converters with the DC block on, whole recording (kernels_dc.hip) ----------------

@@ -331,6 +331,26 @@ __device__ __forceinline__ uint16_t mag_of_sample (const uint16_t *lut, const Sc
   return mag_from_float (float (s[0]) * sc, float (s[1]) * sc, nullptr);
 }
 
+// 16 bytes per lane from per-lane global addresses to consecutive LDS bytes behind a wave-uniform base, no register in
+// between (global_load_lds_dwordx4); the caller waits with s_waitcnt vmcnt(0) in front of its barrier
+__device__ __forceinline__ void glds16 (const uint8_t *src, uint8_t *lds_wave_base)
+{
+  __builtin_amdgcn_global_load_lds ((const __attribute__ ((address_space (1))) void *) src,
+                                    (__attribute__ ((address_space (3))) void *) lds_wave_base, 16, 0, 0);
+}
+
+// Magnitudes that lie in HBM as they are wanted in the tile (kConvMagU16): `bytes` (a multiple of 16) from `src`
+// (16-byte aligned, all readable) to `tile` (16-byte aligned), 1 KiB pieces dealt round the kWaves waves of the workgroup.
+template <int kWaves>
+__device__ __forceinline__ void stage_u16_dma (uint16_t *tile, const uint16_t *src, int bytes, int wv, int lane)
+{
+  const int pieces = bytes >> 10, tail16 = (bytes & 1023) >> 4;
+  const uint8_t *s8 = reinterpret_cast<const uint8_t *> (src);
+  uint8_t *t8 = reinterpret_cast<uint8_t *> (tile);
+  for (int pc = wv; pc < pieces; pc += kWaves) glds16 (s8 + 1024 * pc + 16 * lane, t8 + 1024 * pc);
+  if (tail16 && wv == pieces % kWaves && lane < tail16) glds16 (s8 + 1024 * pieces + 16 * lane, t8 + 1024 * pieces);
+}
+
 // kLanes = 64: a wave stages its own tile; kLanes = 256: the four waves of a workgroup stage a shared tile (lane = threadIdx.x)
 template <int CONV, int kCount, int kLanes = 64>
 __device__ __forceinline__ void stage_tile_pos (uint16_t *tile, const uint16_t *lut, const ScanParams &p, long long s0, int lane)
@@ -378,6 +398,22 @@ __device__ __forceinline__ void stage_tile_pos (uint16_t *tile, const uint16_t *
   }
 }
 
+// sample by sample, every bound checked (first / last tiles of a shard)
+template <int CONV, int kLanes>
+__device__ __forceinline__ void stage_span_slow (uint16_t *tile, const uint16_t *lut, const ScanParams &p, long long s0, int count, int lane)
+{
+  const long long N = (long long) (CONV == kConvMagU16 ? p.navail : p.nsamples);
+  for (int c = lane * 8; c < (count + 7) / 8 * 8; c += kLanes * 8) {
+    uint16_t out[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) out[k] = mag_of_sample<CONV> (lut, p, s0 + c + k, N);
+    uint4 pk;
+    pk.x = out[0] | (uint32_t (out[1]) << 16); pk.y = out[2] | (uint32_t (out[3]) << 16);
+    pk.z = out[4] | (uint32_t (out[5]) << 16); pk.w = out[6] | (uint32_t (out[7]) << 16);
+    *reinterpret_cast<uint4 *> (&tile[c]) = pk;
+  }
+}
+
 // The same with a run-time length (count <= kMaxCount): the windows a workgroup of d8_window_kernel works on at a time
 // lie as far apart as the triggers were.
 template <int CONV, int kMaxCount, int kLanes>
@@ -414,15 +450,7 @@ __device__ __forceinline__ void stage_span_pos (uint16_t *tile, const uint16_t *
     }
     return;
   }
-  for (int c = lane * 8; c < (count + 7) / 8 * 8; c += kLanes * 8) {
-    uint16_t out[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) out[k] = mag_of_sample<CONV> (lut, p, s0 + c + k, N);
-    uint4 pk;
-    pk.x = out[0] | (uint32_t (out[1]) << 16); pk.y = out[2] | (uint32_t (out[3]) << 16);
-    pk.z = out[4] | (uint32_t (out[5]) << 16); pk.w = out[6] | (uint32_t (out[7]) << 16);
-    *reinterpret_cast<uint4 *> (&tile[c]) = pk;
-  }
+  stage_span_slow<CONV, kLanes> (tile, lut, p, s0, count, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -505,12 +533,6 @@ __device__ __forceinline__ void stage_tile_rank8 (uint8_t *tile, const uint8_t *
 // sample a0 + x (a0 a multiple of 16, the tile 16-byte aligned): one global_load_lds_dwordx4 moves 1 KiB (64 lanes x 16
 // bytes) from per-lane source addresses to consecutive LDS bytes without touching a register.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void glds16 (const uint8_t *src, uint8_t *lds_wave_base)
-{
-  __builtin_amdgcn_global_load_lds ((const __attribute__ ((address_space (1))) void *) src,
-                                    (__attribute__ ((address_space (3))) void *) lds_wave_base, 16, 0, 0);
-}
-
 // byte the as-written converter reads for sample n (ref: src/convert.c:19,29): byte n % B of block n / B
 __device__ __forceinline__ const uint8_t *lut_byte_addr_of (const uint8_t *iq, uint32_t block_samples, long long n)
 {

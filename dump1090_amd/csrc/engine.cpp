@@ -170,6 +170,7 @@ struct modes_engine {
   float kernel_ms[2] = { 0, 0 };
   // 8 MS/s
   DevBuf<uint64_t> d8_trig, d8_amb, d8_off;
+  DevBuf<uint16_t> d8_vmag;            // the magnitude plane d8_trig_kernel leaves for the window kernel (2 B per sample)
   DevBuf<uint32_t> d8_p0, d8_mx, d8_win_count, d8_chunk_rec, d8_announce;
   DevBuf<uint8_t> d8_table, d8_entry;
   DevBuf<int64_t> d8_win_start, d8_small;
@@ -1400,6 +1401,12 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   if ((rc = e->d8_small.reserve (16)) != MODES_OK) return rc;
   if ((rc = e->d8_off.reserve (2 * size_t (nchunks) + 2)) != MODES_OK) return rc;
   q.trig = e->d8_trig.p; q.amb = e->d8_amb.p; q.table = e->d8_table.p; q.entry = e->d8_entry.p;
+  // (with the DC block on the magnitudes are in HBM already: prepare_dc made `sp` a kConvMagU16 stream)
+  if (sp.conv != kConvMagU16 && !getenv ("MODES_D8_NO_PLANE")) {
+    const size_t vcap = size_t ((T + 7) & ~7ull) + 1024;         // the window kernel's tiles are fetched in whole 16-byte pieces
+    if ((rc = e->d8_vmag.reserve (vcap)) != MODES_OK) return rc;
+    q.vmag = e->d8_vmag.p; q.vcap = vcap;
+  }
   q.win_start = e->d8_win_start.p; q.win_count = e->d8_win_count.p; q.windows = e->d8_windows.p; q.records = e->d8_records.p;
   // d8_small: [0..3] pre-window list, [4] pending window, [5] amb count (low half) , [6] last ambiguous step + 1
   long long *d_pre = reinterpret_cast<long long *> (e->d8_small.p);
@@ -1697,8 +1704,9 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
     if (timing) fprintf (stderr, "  %.3f ms: range %u: waited %.3f ms for the device", since_entry (), r, std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - t_wait0).count ());
     if (r == 0 && e->d8_planes_timed) (void) hipEventElapsedTime (&e->kernel_ms[1], e->ev[2], e->ev[3]);
     float wms = 0;
-    (void) hipEventElapsedTime (&wms, e->d8_events[3 * r], e->d8_events[3 * r + 1]);
-    e->kernel_ms[0] += wms;
+    // (the ranges' launches overlap: the window kernels' time is the span from the first launch's start to the last one's end)
+    (void) hipEventElapsedTime (&wms, e->d8_events[0], e->d8_events[3 * r + 1]);
+    if (wms > e->kernel_ms[0]) e->kernel_ms[0] = wms;
     const uint64_t *tot = e->pin_tot.p + 4 * r;
     const uint64_t nwin = tot[0], nrec = tot[1];
     if (tot[2] > uint64_t (kD8WinCap)) return fail (MODES_E_OVERFLOW, "a chunk of range %u holds %llu windows (cap %d)", r, (unsigned long long) tot[2], kD8WinCap);

@@ -164,6 +164,21 @@ __device__ __forceinline__ void d8_trig_body (const D8Params &q, uint64_t strip_
     stage_tile_pos<CONV, kTrigGroupTile, 64 * kW8> (w.tile + kTileLead, w.lut, q.sp, slo0, int (threadIdx.x));
   }
   __syncthreads ();
+  if constexpr (!ARRAYS && CONV != kConvMagU16) {
+    // the magnitude plane: the workgroup's own 4 x 2048 positions as they lie in the tile, 16 bytes per thread and go
+    // (the rows it shares with the next workgroup are that one's; what the last workgroup leaves open in front of T is
+    // filled by d8_vmag_fill_kernel)
+    if (q.vmag) {
+      const long long xlo0 = 8 * ((long long) strip0 * kD8StripSteps + 1) - kD8LookAhead;     // a multiple of 8
+#pragma unroll
+      for (int it = 0; it < kW8 * 8 * kD8StripSteps / (8 * 64 * kW8); it++) {
+        const int i8 = 8 * (it * 64 * kW8 + int (threadIdx.x));
+        const long long x = xlo0 + i8;
+        if (x >= 0 && uint64_t (x) + 8 <= q.vcap)
+          *reinterpret_cast<uint4 *> (q.vmag + x) = *reinterpret_cast<const uint4 *> (w.tile + kTileLead + i8);
+      }
+    }
+  }
   if (strip >= nstrips || strip >= strip_limit) return;
   const uint16_t *tile = w.tile + kTileLead + 8 * kD8StripSteps * wv;       // tile[i] = V[x0 + i] for this wave's strip
 
@@ -247,6 +262,16 @@ void d8_trig_arrays_kernel (const D8Params q, uint64_t strip_limit)
 {
   __shared__ TrigLds lds[1];
   d8_trig_body<CONV, true> (q, strip_limit, lds);
+}
+
+// positions [from, to) of the magnitude plane, one by one (what the last workgroup of d8_trig_kernel leaves open)
+template <int CONV>
+__global__ __launch_bounds__ (256)
+void d8_vmag_fill_kernel (const D8Params q, long long from, long long to)
+{
+  const long long x = from + (long long) blockIdx.x * 256 + threadIdx.x;
+  if (x < to && uint64_t (x) < q.vcap)
+    q.vmag[x] = mag_of_V<CONV> (q.sp.iq, q.sp.nsamples, q.sp.halo, q.sp.ov, q.sp.block_samples, q.sp.lut256, x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -605,8 +630,17 @@ __device__ __forceinline__ void d8_window_body (const D8Params &q, Lds *lds, uin
 #pragma unroll 1
       for (int r = 0; r < (shared ? 1 : kW8); r++) {                         // all 256 threads stage: the span, or one window after the other
         const long long x_r = shared ? xlo_min : 8 * ((long long) starts[min (kf + uint32_t (r), nwin - 1)] - 4) - kD8LookAhead;
-        stage_span_pos<CONV, kWinGroupTile, 64 * kW8> (w.tile + r * kWinQuarter, w.lut, q.sp, x_r - ov, shared ? int (span) : kWinNeed, int (threadIdx.x));
+        const int cnt = shared ? int (span) : kWinNeed;
+        if constexpr (CONV == kConvMagU16) {
+          // the tile is a copy of what lies in HBM (x_r is a multiple of 8): LDS-DMA, no register and no VALU work
+          const uint16_t *src = reinterpret_cast<const uint16_t *> (q.sp.iq) + x_r;
+          const int bytes = (2 * cnt + 15) & ~15;
+          if (x_r >= 0 && uint64_t (x_r) + uint64_t (bytes / 2) <= q.sp.navail && !(reinterpret_cast<uintptr_t> (src) & 15))
+            stage_u16_dma<kW8> (w.tile + r * kWinQuarter, src, bytes, wv, lane0);
+          else stage_span_slow<CONV, 64 * kW8> (w.tile + r * kWinQuarter, w.lut, q.sp, x_r, cnt, int (threadIdx.x));
+        } else stage_span_pos<CONV, kWinGroupTile, 64 * kW8> (w.tile + r * kWinQuarter, w.lut, q.sp, x_r - ov, cnt, int (threadIdx.x));
       }
+      if constexpr (CONV == kConvMagU16) asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");       // the DMA writes land before the barrier lets anyone read
       __syncthreads ();
       if (!my) continue;
     } else {
@@ -787,7 +821,7 @@ void d8_window_kernel (const D8Params q)
 {
   // the float converters hold too many registers through a staging pass of four rounds of 256 threads, and the magnitudes
   // of the drop-in boundary have nothing to convert: those keep a tile per wave
-  constexpr bool kGroup = CONV != kConvSc16Generic && CONV != kConvSc16Q11Generic && CONV != kConvMagU16;
+  constexpr bool kGroup = CONV != kConvSc16Generic && CONV != kConvSc16Q11Generic;
   __shared__ std::conditional_t<kGroup, WinGroupLds, WinLds> lds[kGroup ? 1 : kW8];
   __shared__ uint32_t crc_tab[256];
   d8_window_body<CONV, true> (q, lds, crc_tab);
@@ -1007,7 +1041,15 @@ hipError_t launch_d8_trig (const D8Params &q, uint64_t step_limit, hipStream_t s
   if (step_limit) nstrips = min (nstrips, (step_limit + kD8StripSteps - 1) / kD8StripSteps);
   const dim3 grid ((unsigned) ((nstrips + kW8 - 1) / kW8)), block (64 * kW8);
   if (q.write_arrays) { D8_DISPATCH (d8_trig_arrays_kernel, grid, block, q, nstrips); }
-  else { D8_DISPATCH (d8_trig_kernel, grid, block, q, nstrips); }
+  else {
+    D8_DISPATCH (d8_trig_kernel, grid, block, q, nstrips);
+    if (q.vmag && q.sp.conv != kConvMagU16 && !step_limit) {
+      // the strips' own positions end at 2048 * (workgroups) - 536: the rest of [0, T) one by one
+      const long long own_end = 8ll * kD8StripSteps * kW8 * (long long) grid.x + 8 - kD8LookAhead;
+      const long long from = own_end > 0 ? own_end : 0, to = (long long) q.T;
+      if (to > from) { D8_DISPATCH (d8_vmag_fill_kernel, dim3 ((unsigned) ((to - from + 255) / 256)), dim3 (256), q, from, to); }
+    }
+  }
   return hipGetLastError ();
 }
 
@@ -1044,7 +1086,15 @@ hipError_t launch_d8_windows (const D8Params &q, uint32_t nch, hipStream_t strea
 {
   if (nch == 0) return hipSuccess;
   const dim3 grid (nch, D8_WIN_GRIDY), block (64 * kW8);
-  if (which & 1) { D8_DISPATCH (d8_window_kernel, grid, block, q); }
+  if (which & 1) {
+    if (q.vmag && q.sp.conv != kConvMagU16) {
+      // the plane d8_trig_kernel left: the tiles are copies, nothing is converted a second time
+      D8Params qm = q;
+      qm.sp.conv = kConvMagU16; qm.sp.iq = reinterpret_cast<const uint8_t *> (q.vmag); qm.sp.navail = q.vcap;     // (all of it readable; a plain window reads nothing at or beyond T)
+      qm.sp.halo = nullptr; qm.sp.ov = 0;
+      hipLaunchKernelGGL (d8_window_kernel<kConvMagU16>, grid, block, 0, stream, qm);
+    } else { D8_DISPATCH (d8_window_kernel, grid, block, q); }
+  }
   // a few windows per block edge: fewer, longer-lived waves (each looks at 64 windows per pass)
   const dim3 edge_grid (nch, 4);
   if (which & 2) { D8_DISPATCH (d8_window_edge_kernel, edge_grid, block, q); }
