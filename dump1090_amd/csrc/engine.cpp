@@ -222,6 +222,7 @@ struct modes_engine {
   uint64_t d8_last_chunks = 0, d8_last_nwin = 0, d8_last_nrec = 0, d8_last_msgs = 0;   // the last run: sizes the next run's arrays                  // 8 MS/s: signal sums of the accepted messages, range by range
   std::vector<hipEvent_t> d8_gathered;        // one per range of chunks: its packed windows / records are in pinned memory
   hipEvent_t d8_chain_done = nullptr;
+  std::vector<hipEvent_t> d8_trig_ev, d8_chain_ev;      // pipelined run_8000: around every range's planes / behind its chain
   std::vector<hipEvent_t> d8_lvl_ev;                             // [range]: the range's signal levels are in pinned memory
   std::vector<hipEvent_t> d8_edge_ev;                            // [range]: the range's windows at block edges are done   // the window list stands / the windows at block edges are done
   std::vector<hipEvent_t> d8_events;          // three per range of chunks: windows begin / end, counts (then records) on the host
@@ -1032,6 +1033,8 @@ void modes_engine_destroy (modes_engine *e)
   for (hipEvent_t ev : e->d8_gathered) if (ev) (void) hipEventDestroy (ev);
   if (e->d8_chain_done) (void) hipEventDestroy (e->d8_chain_done);
   for (hipEvent_t ev : e->d8_edge_ev) (void) hipEventDestroy (ev);
+  for (hipEvent_t ev : e->d8_trig_ev) (void) hipEventDestroy (ev);
+  for (hipEvent_t ev : e->d8_chain_ev) (void) hipEventDestroy (ev);
   for (hipEvent_t ev : e->d8_lvl_ev) (void) hipEventDestroy (ev);
   if (e->tabs.short_tab) (void) hipFree (e->tabs.short_tab);
   if (e->tabs.long_tab) (void) hipFree (e->tabs.long_tab);
@@ -1326,7 +1329,7 @@ static int run_mode_ac_2400 (modes_engine *e, const void *d_iq, size_t nbytes, u
 // window chain leaves the shard for every state it can be entered in; nothing is decoded and the state set for the run
 // stays set.
 static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t first_sample, const uint16_t *d_halo,
-                     hipStream_t stream, int32_t *chain_map = nullptr)
+                     hipStream_t stream, int32_t *chain_map = nullptr, bool allow_pipeline = true)
 {
   if (first_sample % e->block_samples && nbytes / bytes_per_sample (e->cfg.input_format) > e->block_samples)
     return fail (MODES_E_ARG, "first_sample must be a multiple of the block length");
@@ -1400,6 +1403,15 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   if ((rc = e->d8_records.reserve (size_t (nchunks) * kD8WinCap * kD8Cand)) != MODES_OK) return rc;
   if ((rc = e->d8_small.reserve (16)) != MODES_OK) return rc;
   if ((rc = e->d8_off.reserve (2 * size_t (nchunks) + 2)) != MODES_OK) return rc;
+  // the ranges of chunks the run is decoded in (below)
+  uint32_t nranges = nchunks >= 256 ? 8u : nchunks >= 16 ? 4u : 1u;
+  if (const char *ev = getenv ("MODES_RANGES")) { const int v = atoi (ev); if (v >= 1 && v <= 64) nranges = uint32_t (v) < nchunks ? uint32_t (v) : nchunks; }
+  std::vector<uint32_t> lo (nranges + 1);
+  {
+    // equal ranges (a small first or last range, or more ranges, were measured in the pipelined run too: nothing in it)
+    for (uint32_t r = 0; r < nranges; r++) lo[r] = uint32_t (uint64_t (nchunks) * r / nranges);
+    lo[nranges] = nchunks;
+  }
   q.trig = e->d8_trig.p; q.amb = e->d8_amb.p; q.table = e->d8_table.p; q.entry = e->d8_entry.p;
   // (with the DC block on the magnitudes are in HBM already: prepare_dc made `sp` a kConvMagU16 stream)
   if (sp.conv != kConvMagU16 && !getenv ("MODES_D8_NO_PLANE")) {
@@ -1428,6 +1440,14 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   const bool same_windows = reuse && !chain_map && e->d8_win_gen == e->d8_planes_gen && e->d8_win_pending == (long long) q.pending &&
                             e->d8_win_tail == trig_tail_in;
   if (!chain_map) e->d8_win_gen = ~0ull;
+  // Pipelined: the trigger planes and the chain are formed range by range too, in front of each range's windows, so the
+  // host's ordered walk starts behind the first range instead of behind the whole recording's planes, and nothing waits
+  // for the host between the planes and the windows.  It rests on the bet that no step needs the running average (none
+  // does unless the input is near-silent); a range that shows such a step ends the bet and the run starts again the
+  // plain way.
+  const bool pipelined = allow_pipeline && !reuse && !chain_map && nranges > 1 && !getenv ("MODES_D8_NO_PIPELINE");
+  std::vector<uint32_t> cache_at_entry;
+  if (pipelined) cache_at_entry.assign (e->cache.raw (), e->cache.raw () + kIcaoSlots);
   if (reuse) {
     const long long init[5] = { 0, 0, 0, 0, 1 };                  // the pre-window list and the open window; counts and planes stay
     if (!same_windows) HIP_TRY (hipMemcpyAsync (d_pre, init, sizeof init, hipMemcpyHostToDevice, stream));
@@ -1438,10 +1458,12 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
     HIP_TRY (hipMemcpyAsync (d_pre, init, sizeof init, hipMemcpyHostToDevice, stream));
     HIP_TRY (hipMemsetAsync (q.trig, 0, nwords * sizeof (uint64_t), stream));
     HIP_TRY (hipMemsetAsync (q.amb, 0, nwords * sizeof (uint64_t), stream));
+  }
+  if (!reuse && !pipelined) {
     HIP_TRY (hipEventRecord (e->ev[2], stream));
     HIP_TRY (launch_d8_trig (q, 0, stream));
     HIP_TRY (hipEventRecord (e->ev[3], stream));
-    HIP_TRY (launch_d8_last_amb (q.amb, nwords, d_limit, stream));
+    HIP_TRY (launch_d8_last_amb (q.amb, 0, nwords, d_limit, nullptr, stream));
     HIP_TRY (hipMemcpyAsync (&limit, d_limit, sizeof limit, hipMemcpyDeviceToHost, stream));
     HIP_TRY (hipStreamSynchronize (stream));
     if (timing) fprintf (stderr, "  %.3f ms: trigger planes done\n", since_entry ());
@@ -1458,8 +1480,8 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
       HIP_TRY (launch_d8_acc (q, limit, nullptr, stream));
     }
     HIP_TRY (launch_d8_chain_table (q, stream));
-    e->d8_planes_gen++;
   }
+  if (!reuse) e->d8_planes_gen++;
   e->d8_planes_key = key; e->d8_planes_limit = limit;
   if (have_in) memcpy (e->d8_planes_dprev, e->d8_in.dprev, sizeof e->d8_planes_dprev);
   e->d8_planes_timed = !reuse;
@@ -1489,7 +1511,7 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
     e->d8_reuse = true;
     return MODES_OK;
   }
-  e->d8_planes_valid = true;
+  if (!pipelined) e->d8_planes_valid = true;                       // (pipelined: when the last range's are there, at the end)
   // addresses the run can know: what the cache starts with, plus every address the window kernel sees announced
   q.announce = e->d8_announce.p;
   {
@@ -1505,20 +1527,22 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
       HIP_TRY (launch_d8_seed (q.announce, e->small_u32.p, nseed, stream));
     }
   }
-  if (!same_windows) HIP_TRY (launch_d8_chain (q, trig_tail_in, 0ll, d_pre, d_pending, stream));
-  {
+  if (!same_windows && !pipelined) HIP_TRY (launch_d8_chain (q, trig_tail_in, 0ll, d_pre, d_pending, stream));
+  auto queue_hand_over = [&] (hipStream_t hs) -> int {
     // what this run leaves for the shard behind it: the last 1928 differences, the open window, the last 64 trigger
     // decisions (read back with the first range's counts below); acc only on request (modes_engine_get_d8_state)
     int rc_out;
     if ((rc_out = e->d8_dnext.reserve (kD8Overlap)) != MODES_OK) return rc_out;
     if ((rc_out = e->pin_d8.reserve (kD8Overlap + 16)) != MODES_OK) return rc_out;
-    HIP_TRY (launch_d8_tail (q, e->d8_dnext.p, stream));
-    HIP_TRY (hipMemcpyAsync (e->pin_d8.p, e->d8_dnext.p, kD8Overlap * sizeof (int32_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY (hipMemcpyAsync (e->pin_d8.p + kD8Overlap, d_pending, sizeof (long long), hipMemcpyDeviceToHost, stream));
+    HIP_TRY (launch_d8_tail (q, e->d8_dnext.p, hs));
+    HIP_TRY (hipMemcpyAsync (e->pin_d8.p, e->d8_dnext.p, kD8Overlap * sizeof (int32_t), hipMemcpyDeviceToHost, hs));
+    HIP_TRY (hipMemcpyAsync (e->pin_d8.p + kD8Overlap, d_pending, sizeof (long long), hipMemcpyDeviceToHost, hs));
     const size_t w_last = size_t ((q.nsteps - 1) >> 6);
-    HIP_TRY (hipMemcpyAsync (e->pin_d8.p + kD8Overlap + 2, q.trig + (w_last ? w_last - 1 : 0), (w_last ? 2 : 1) * sizeof (uint64_t), hipMemcpyDeviceToHost, stream));
-    HIP_TRY (hipMemcpyAsync (e->pin_d8.p + kD8Overlap + 6, q.amb_count, sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
-  }
+    HIP_TRY (hipMemcpyAsync (e->pin_d8.p + kD8Overlap + 2, q.trig + (w_last ? w_last - 1 : 0), (w_last ? 2 : 1) * sizeof (uint64_t), hipMemcpyDeviceToHost, hs));
+    HIP_TRY (hipMemcpyAsync (e->pin_d8.p + kD8Overlap + 6, q.amb_count, sizeof (uint32_t), hipMemcpyDeviceToHost, hs));
+    return MODES_OK;
+  };
+  if (!pipelined && (rc = queue_hand_over (stream)) != MODES_OK) return rc;
   e->d8_q = q; e->d8_limit = limit; e->d8_trig_tail_in = trig_tail_in;
   // The completed windows in ranges of chunks.  Everything the device does for a range is queued up front on the
   // caller's stream, all ranges back to back: windows, count (address filter), offsets (one wave: where each chunk's
@@ -1529,8 +1553,6 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   // in ranges <= r (or cached at the start), and count(r) runs behind windows(r), so the address filter sees all it needs.
   // The pinned arrays are sized from the last run (or a default per chunk); a range that does not fit is gathered again
   // into arrays of the right size.
-  uint32_t nranges = nchunks >= 256 ? 8u : nchunks >= 16 ? 4u : 1u;
-  if (const char *ev = getenv ("MODES_RANGES")) { const int v = atoi (ev); if (v >= 1 && v <= 64) nranges = uint32_t (v) < nchunks ? uint32_t (v) : nchunks; }
   if (e->d8_events.size () < 3 * size_t (nranges)) {
     const size_t have = e->d8_events.size ();
     e->d8_events.resize (3 * size_t (nranges), nullptr);
@@ -1551,17 +1573,6 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   if (!e->copy_stream) HIP_TRY (hipStreamCreateWithFlags (&e->copy_stream, hipStreamNonBlocking));
   hipStream_t side = e->post_stream, lvl = e->copy_stream;       // gathers (queued up front) / signal levels (queued range by range)
   struct Drain { hipStream_t a, b, c; ~Drain () { (void) hipStreamSynchronize (a); (void) hipStreamSynchronize (b); (void) hipStreamSynchronize (c); } } drain = { side, lvl, stream };
-  std::vector<uint32_t> lo (nranges + 1);
-  {
-    // equal ranges: the walk over a range takes the host about as long as the range takes the device, so the host
-    // follows one range behind and what is left when the last window kernel ends is the walk over one range
-    const double ratio = 1.0;
-    double wsum = 0, run = 0, w = 1.0;
-    for (uint32_t r = 0; r < nranges; r++, w *= ratio) wsum += w;
-    w = 1.0;
-    for (uint32_t r = 0; r < nranges; r++, w *= ratio) { lo[r] = uint32_t (double (nchunks) * run / wsum); run += w; }
-    lo[nranges] = nchunks;
-  }
   // per-chunk budget of the pinned arrays
   uint64_t bw = 192, br = 256;
   if (e->d8_last_chunks) {
@@ -1572,13 +1583,104 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   if ((rc = e->pin_wins.reserve (size_t (nchunks) * bw)) != MODES_OK) return rc;
   if ((rc = e->pin_recs.reserve (size_t (nchunks) * br + 1)) != MODES_OK) return rc;
   if ((rc = e->d8_tot.reserve (4 * size_t (nranges))) != MODES_OK) return rc;
-  if ((rc = e->pin_tot.reserve (4 * size_t (nranges))) != MODES_OK) return rc;
+  if ((rc = e->pin_tot.reserve (4 * size_t (nranges) + 4)) != MODES_OK) return rc;      // + needs_average, limit_host
+  // pipelined: set by the device when a range holds a step that needs the running average
+  volatile uint32_t *const needs_average = reinterpret_cast<volatile uint32_t *> (e->pin_tot.p + 4 * size_t (nranges));
+  *needs_average = 0;
   // the few windows at block edges are slow ones (a few waves that wait a lot): the first range's in front of its
   // other windows, every other range's in a launch of its own on the stream of the signal levels beside them (idle
   // until the first walk is over) -- 0.1-0.2 ms each there, through long before the range's other windows are.  (All of
   // them in one launch took 0.7-1.3 ms beside the window kernels and the second range waited for it: the host stood
   // still for 0.6 ms and never made that up.)
-  if (!same_windows) {
+  if (pipelined) {
+    // caller's stream: planes (0), planes (1), windows (0), planes (2), windows (1), ... -- the windows of a range read the
+    // magnitude plane a little into the next range's; second stream: chain (0), chain (1), edge windows / count / gather (0),
+    // chain (2), ... -- a range's chain (small kernels that leave the GPU nearly empty) runs beside the next range's planes.
+    while (e->d8_trig_ev.size () < 2 * size_t (nranges)) {
+      hipEvent_t ev;
+      HIP_TRY (hipEventCreate (&ev));
+      e->d8_trig_ev.push_back (ev);
+    }
+    while (e->d8_chain_ev.size () < nranges) {
+      hipEvent_t ev;
+      HIP_TRY (hipEventCreateWithFlags (&ev, hipEventDisableTiming));
+      e->d8_chain_ev.push_back (ev);
+    }
+    constexpr uint64_t kChunkWords = kD8ChunkSteps / 64;
+    auto queue_planes = [&] (uint32_t r) -> int {
+      const uint32_t c0 = lo[r], n = lo[r + 1] - c0;
+      const bool last = r + 1 == nranges;
+      HIP_TRY (hipEventRecord (e->d8_trig_ev[2 * r], stream));
+      HIP_TRY (launch_d8_trig (q, 0, stream, c0, last ? 0 : n));
+      HIP_TRY (hipEventRecord (e->d8_trig_ev[2 * r + 1], stream));
+      const uint64_t w1 = last ? uint64_t (nwords) : std::min (uint64_t (nwords), uint64_t (lo[r + 1]) * kChunkWords);
+      // (the first range's such steps -- the stream's first steps nearly always are -- get their average below)
+      HIP_TRY (launch_d8_last_amb (q.amb, uint64_t (c0) * kChunkWords, w1, d_limit, r ? const_cast<uint32_t *> (needs_average) : nullptr, stream));
+      return MODES_OK;
+    };
+    auto queue_chain = [&] (uint32_t r, hipEvent_t planes_done) -> int {
+      const uint32_t c0 = lo[r], n = lo[r + 1] - c0;
+      const bool last = r + 1 == nranges;
+      HIP_TRY (hipStreamWaitEvent (side, planes_done, 0));
+      HIP_TRY (launch_d8_chain_table (q, side, c0, n));
+      HIP_TRY (launch_d8_chain (q, trig_tail_in, 0ll, d_pre, d_pending, side, c0, last ? 0 : n));
+      HIP_TRY (hipEventRecord (e->d8_chain_ev[r], side));
+      return last ? queue_hand_over (side) : MODES_OK;
+    };
+    auto queue_windows = [&] (uint32_t k) -> int {
+      const uint32_t c0 = lo[k], n = lo[k + 1] - c0;
+      q.chunk0 = c0;
+      HIP_TRY (hipStreamWaitEvent (stream, e->d8_chain_ev[k], 0));
+      HIP_TRY (hipEventRecord (e->d8_events[3 * k], stream));
+      HIP_TRY (launch_d8_windows (q, n, stream, 1));                 // (a stream of their own beside the planes: measured, no gain)
+      HIP_TRY (hipEventRecord (e->d8_events[3 * k + 1], stream));
+      HIP_TRY (launch_d8_windows (q, n, side, 2));                 // the few windows at block edges, beside the others
+      HIP_TRY (hipStreamWaitEvent (side, e->d8_events[3 * k + 1], 0));
+      HIP_TRY (launch_d8_count (q, n, e->d8_chunk_rec.p, side));
+      HIP_TRY (launch_d8_offsets (e->d8_chunk_rec.p, e->d8_win_count.p, nchunks, c0, n, e->d8_off.p, e->d8_off.p + nchunks + 1,
+                                  uint64_t (n) * bw, uint64_t (n) * br, e->d8_tot.p + 4 * k, e->pin_tot.p + 4 * k, side));
+      HIP_TRY (launch_d8_gather (q, n, e->d8_off.p, e->d8_off.p + nchunks + 1, e->pin_wins.p + size_t (c0) * bw, e->pin_recs.p + size_t (c0) * br,
+                                 side, e->d8_tot.p + 4 * k));
+      HIP_TRY (hipEventRecord (e->d8_gathered[k], side));
+      return MODES_OK;
+    };
+    // the first range's planes, and whether its first steps need the running average (the host looks while the second
+    // range's planes are being formed)
+    volatile uint32_t *const limit_host = needs_average + 2;
+    limit_host[0] = limit_host[1] = 0;
+    if ((rc = queue_planes (0)) != MODES_OK) return rc;
+    HIP_TRY (launch_copy_u32 (const_cast<uint32_t *> (limit_host), reinterpret_cast<const uint32_t *> (d_limit), 2, stream));
+    HIP_TRY (hipEventRecord (e->d8_chain_done, stream));
+    if ((rc = queue_planes (1)) != MODES_OK) return rc;
+    HIP_TRY (hipEventSynchronize (e->d8_chain_done));
+    limit = uint64_t (limit_host[0]) | uint64_t (limit_host[1]) << 32;
+    if (timing) fprintf (stderr, "  %.3f ms: planes of range 0 done, %llu steps up to the last that needs the running average\n", since_entry (), limit);
+    hipEvent_t planes0 = e->d8_trig_ev[1];
+    if (limit) {
+      if (have_in && !e->d8_in.acc_valid)
+        return fail (MODES_E_ARG, "demod_8000: this shard holds steps whose trigger depends on the running average (near-silent input): "
+                                  "the state handed over must carry acc (modes_engine_get_d8_state with want_acc)");
+      if ((rc = e->d8_p0.reserve (size_t (q.nsteps) + 64)) != MODES_OK) return rc;
+      if ((rc = e->d8_mx.reserve (size_t (q.nsteps) + 64)) != MODES_OK) return rc;
+      q.p0 = e->d8_p0.p; q.mx = e->d8_mx.p; q.write_arrays = 1;
+      HIP_TRY (launch_d8_trig (q, limit, stream));                  // only the strips up to the last such step
+      q.write_arrays = 0;
+      HIP_TRY (launch_d8_acc (q, limit, nullptr, stream));
+      HIP_TRY (hipEventRecord (e->d8_chain_done, stream));
+      planes0 = e->d8_chain_done;
+      e->d8_planes_limit = limit; e->d8_limit = limit; e->d8_q = q;
+    }
+    if ((rc = queue_chain (0, planes0)) != MODES_OK) return rc;
+    if ((rc = queue_chain (1, e->d8_trig_ev[3])) != MODES_OK) return rc;
+    if ((rc = queue_windows (0)) != MODES_OK) return rc;
+    for (uint32_t r = 2; r < nranges; r++) {
+      if ((rc = queue_planes (r)) != MODES_OK) return rc;
+      if ((rc = queue_chain (r, e->d8_trig_ev[2 * r + 1])) != MODES_OK) return rc;
+      if ((rc = queue_windows (r - 1)) != MODES_OK) return rc;
+    }
+    if ((rc = queue_windows (nranges - 1)) != MODES_OK) return rc;
+  }
+  if (!same_windows && !pipelined) {
     q.chunk0 = 0;
     HIP_TRY (launch_d8_windows (q, lo[1], stream, 2));
     if (nranges > 1) {
@@ -1591,7 +1693,7 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
       }
     }
   }
-  for (uint32_t r = 0; r < nranges; r++) {
+  for (uint32_t r = 0; r < nranges && !pipelined; r++) {
     const uint32_t c0 = lo[r], n = lo[r + 1] - c0;
     q.chunk0 = c0;
     HIP_TRY (hipEventRecord (e->d8_events[3 * r], stream));
@@ -1702,11 +1804,27 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
     const auto t_wait0 = std::chrono::steady_clock::now ();
     HIP_TRY (hipEventSynchronize (e->d8_gathered[r]));
     if (timing) fprintf (stderr, "  %.3f ms: range %u: waited %.3f ms for the device", since_entry (), r, std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - t_wait0).count ());
-    if (r == 0 && e->d8_planes_timed) (void) hipEventElapsedTime (&e->kernel_ms[1], e->ev[2], e->ev[3]);
+    if (pipelined && *needs_average) {
+      // the bet is lost: nothing of this run stands; the engine as it was entered, and the plain way
+      if (timing) fprintf (stderr, "\n  %.3f ms: a step of range %u needs the running average: once more, planes first\n", since_entry (), r);
+      HIP_TRY (hipStreamSynchronize (side)); HIP_TRY (hipStreamSynchronize (lvl)); HIP_TRY (hipStreamSynchronize (stream));
+      memcpy (e->cache.raw (), cache_at_entry.data (), kIcaoSlots * sizeof (uint32_t));
+      e->messages.swap (e->d8_prev_msgs);
+      e->d8_msgs_serial = e->d8_prev_serial;
+      e->d8_in_set = have_in;
+      e->tail_half ^= 1;
+      const int rc_again = run_8000 (e, d_iq, nbytes, first_sample, d_halo, stream, chain_map, false);
+      e->stats.scan_retries++;
+      return rc_again;
+    }
     float wms = 0;
-    // (the ranges' launches overlap: the window kernels' time is the span from the first launch's start to the last one's end)
-    (void) hipEventElapsedTime (&wms, e->d8_events[0], e->d8_events[3 * r + 1]);
-    if (wms > e->kernel_ms[0]) e->kernel_ms[0] = wms;
+    if (pipelined) {
+      if (r == 0) e->kernel_ms[1] = 0;
+      (void) hipEventElapsedTime (&wms, e->d8_trig_ev[2 * r], e->d8_trig_ev[2 * r + 1]);
+      e->kernel_ms[1] += wms;
+    } else if (r == 0 && e->d8_planes_timed) (void) hipEventElapsedTime (&e->kernel_ms[1], e->ev[2], e->ev[3]);
+    (void) hipEventElapsedTime (&wms, e->d8_events[3 * r], e->d8_events[3 * r + 1]);
+    e->kernel_ms[0] += wms;
     const uint64_t *tot = e->pin_tot.p + 4 * r;
     const uint64_t nwin = tot[0], nrec = tot[1];
     if (tot[2] > uint64_t (kD8WinCap)) return fail (MODES_E_OVERFLOW, "a chunk of range %u holds %llu windows (cap %d)", r, (unsigned long long) tot[2], kD8WinCap);
@@ -1787,6 +1905,7 @@ static int run_8000 (modes_engine *e, const void *d_iq, size_t nbytes, uint64_t 
   const auto t_end0 = std::chrono::steady_clock::now ();
   HIP_TRY (hipStreamSynchronize (lvl));
   HIP_TRY (hipStreamSynchronize (stream));
+  if (pipelined) { HIP_TRY (hipStreamSynchronize (side)); e->d8_planes_valid = true; }
   if (timing) fprintf (stderr, "  %.3f ms: end: %.3f ms for the streams to drain\n", since_entry (), std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - t_end0).count ());
   e->d8_win_gen = e->d8_planes_gen; e->d8_win_pending = (long long) q.pending; e->d8_win_tail = trig_tail_in;
   if (!stopped_early) { e->d8_last_chunks = nchunks; e->d8_last_nwin = all_win; e->d8_last_nrec = all_rec; }   // (what sizes the next run's arrays)

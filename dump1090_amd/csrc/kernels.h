@@ -19,13 +19,13 @@ hipError_t launch_noise_level (const double *mean_power, uint32_t nblocks, uint3
 hipError_t launch_block_power (const ScanParams &p, uint32_t nblocks, double *mean_power, hipStream_t stream);
 // kernels_8000.hip
 hipError_t upload_constants_8000 (const uint32_t *single_bit, const float *uc8_float);
-hipError_t launch_d8_trig (const D8Params &q, uint64_t step_limit, hipStream_t stream);
+hipError_t launch_d8_trig (const D8Params &q, uint64_t step_limit, hipStream_t stream, uint32_t c_begin = 0, uint32_t c_count = 0);   // chunks [c_begin, + c_count), 0: to the end
 hipError_t launch_d8_acc (const D8Params &q, uint64_t limit, int32_t *acc_out, hipStream_t stream);
-hipError_t launch_d8_last_amb (const uint64_t *amb, uint64_t nwords, unsigned long long *limit, hipStream_t stream);
-hipError_t launch_d8_chain_table (const D8Params &q, hipStream_t stream);
+hipError_t launch_d8_last_amb (const uint64_t *amb, uint64_t w_begin, uint64_t w_end, unsigned long long *limit, uint32_t *flag_host, hipStream_t stream);
+hipError_t launch_d8_chain_table (const D8Params &q, hipStream_t stream, uint32_t c_begin = 0, uint32_t c_count = 0);
 hipError_t launch_d8_chain_exit (const D8Params &q, int32_t *exit_of, hipStream_t stream);
 hipError_t launch_d8_chain (const D8Params &q, unsigned long long trig_tail, long long search0, long long *pre,
-                            long long *pending_out, hipStream_t stream);
+                            long long *pending_out, hipStream_t stream, uint32_t c_begin = 0, uint32_t c_count = 0);
 hipError_t launch_d8_windows (const D8Params &q, uint32_t nch, hipStream_t stream, int which = 3);   // chunks q.chunk0 .. + nch; 1: inside a block, 2: at a block edge
 hipError_t launch_d8_tail (const D8Params &q, int32_t *dnext, hipStream_t stream);
 hipError_t launch_d8_seed (uint32_t *announce, const uint32_t *addr, uint32_t n, hipStream_t stream);

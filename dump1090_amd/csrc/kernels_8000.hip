@@ -147,13 +147,13 @@ __device__ __forceinline__ int table_lookup8 (const ErrEntry *tab, int n, uint32
 // per step: the 8 sliding sums, their maximum, and whether the search would open a window there
 // ---------------------------------------------------------------------------------------------
 template <int CONV, bool ARRAYS>
-__device__ __forceinline__ void d8_trig_body (const D8Params &q, uint64_t strip_limit, TrigLds *lds)
+__device__ __forceinline__ void d8_trig_body (const D8Params &q, uint64_t strip_limit, TrigLds *lds, uint32_t wg_begin)
 {
   const int lane = lane_id ();
   const int wv = __builtin_amdgcn_readfirstlane (int (threadIdx.x >> 6));    // wave-uniform: what derives from it is scalar arithmetic
   TrigLds &w = lds[0];
   const uint64_t nstrips = (q.nsteps + kD8StripSteps - 1) / kD8StripSteps;
-  const uint64_t strip0 = uint64_t (blockIdx.x) * kW8, strip = strip0 + wv;
+  const uint64_t strip0 = (uint64_t (blockIdx.x) + wg_begin) * kW8, strip = strip0 + wv;
   if (strip0 >= nstrips || strip0 >= strip_limit) return;                   // (the whole workgroup)
   if (threadIdx.x < 256) w.lut[threadIdx.x] = q.sp.lut256 ? q.sp.lut256[threadIdx.x] : uint16_t (0);
   __syncthreads ();
@@ -249,19 +249,19 @@ __device__ __forceinline__ void d8_trig_body (const D8Params &q, uint64_t strip_
 
 template <int CONV>
 __global__ __launch_bounds__ (64 * kW8) __attribute__ ((amdgpu_waves_per_eu (D8TRIG_WAVES, D8TRIG_WAVES)))
-void d8_trig_kernel (const D8Params q, uint64_t strip_limit)
+void d8_trig_kernel (const D8Params q, uint64_t strip_limit, uint32_t wg_begin)
 {
   __shared__ TrigLds lds[1];
-  d8_trig_body<CONV, false> (q, strip_limit, lds);
+  d8_trig_body<CONV, false> (q, strip_limit, lds, wg_begin);
 }
 
 // the same, and the per-step sums and maxima written out (drop-in boundary, the slow average's steps)
 template <int CONV>
 __global__ __launch_bounds__ (64 * kW8)
-void d8_trig_arrays_kernel (const D8Params q, uint64_t strip_limit)
+void d8_trig_arrays_kernel (const D8Params q, uint64_t strip_limit, uint32_t wg_begin)
 {
   __shared__ TrigLds lds[1];
-  d8_trig_body<CONV, true> (q, strip_limit, lds);
+  d8_trig_body<CONV, true> (q, strip_limit, lds, wg_begin);
 }
 
 // positions [from, to) of the magnitude plane, one by one (what the last workgroup of d8_trig_kernel leaves open)
@@ -363,11 +363,11 @@ __device__ __forceinline__ void d8_sub_tables (const u64 *bm, int len, uint8_t (
 
 // table[chunk][r] = where the search stands, relative to the end of the chunk, when it entered at offset r
 __global__ __launch_bounds__ (kD8ChainThreads)
-void d8_chain_table_kernel (const D8Params q)
+void d8_chain_table_kernel (const D8Params q, uint32_t c_begin)
 {
   __shared__ u64 bm[kD8ChunkSteps / 64];
   __shared__ __attribute__ ((aligned (16))) uint8_t sub_tab[2 * kD8Subs][128];         // exits, then counts
-  const uint32_t c = blockIdx.x;
+  const uint32_t c = c_begin + blockIdx.x;
   const long long n_lo = (long long) c * kD8ChunkSteps, n_hi = min (n_lo + (long long) kD8ChunkSteps, (long long) q.nsteps);
   const int nwords = int ((n_hi - n_lo + 63) >> 6);
   for (int i = threadIdx.x; i < kD8ChunkSteps / 64; i += kD8ChainThreads) bm[i] = i < nwords ? q.trig[(n_lo >> 6) + i] : 0;
@@ -392,28 +392,32 @@ constexpr int kD8Group = 64;
 __device__ __forceinline__ uint8_t *group_tables (const D8Params &q) { return q.table + size_t (q.nchunks) * D8_TABLE_BYTES_PER_CHUNK; }
 
 __global__ __launch_bounds__ (128)
-void d8_chain_group_kernel (const D8Params q)
+void d8_chain_group_kernel (const D8Params q, uint32_t g_begin)
 {
   __shared__ __attribute__ ((aligned (16))) uint8_t tab[kD8Group * 128];
-  const uint32_t c0 = blockIdx.x * kD8Group, n = min (uint32_t (kD8Group), q.nchunks - c0);
+  const uint32_t g = g_begin + blockIdx.x;
+  const uint32_t c0 = g * kD8Group, n = min (uint32_t (kD8Group), q.nchunks - c0);
   const uint4 *src = reinterpret_cast<const uint4 *> (q.table + size_t (c0) * 128);
   for (uint32_t i = threadIdx.x; i < n * 8; i += 128) reinterpret_cast<uint4 *> (tab)[i] = src[i];
   __syncthreads ();
   const uint32_t r = threadIdx.x;
   uint32_t e = r < uint32_t (kD8Net) ? r : 0u;
   for (uint32_t c = 0; c < n; c++) e = tab[c * 128 + e];
-  group_tables (q)[size_t (blockIdx.x) * 128 + r] = uint8_t (e);
+  group_tables (q)[size_t (g) * 128 + r] = uint8_t (e);
 }
 
 // One thread: what happens before step 0 (a window carried in, triggers among the last steps of the previous
 // call, ref: :493-496 re-scans them), then the entry offset of every group of chunks (entry[kD8Group * g]).
 // pre[0] = count, pre[1..2] = window starts (< 0) found there.
 __global__ __launch_bounds__ (256)
-void d8_chain_resolve_kernel (const D8Params q, u64 trig_tail, long long search0, long long *pre)
+void d8_chain_resolve_kernel (const D8Params q, u64 trig_tail, long long search0, long long *pre, uint32_t g_begin, uint32_t g_end)
 {
+  // groups [g_begin, g_end) of the chain: the first call (g_begin == 0) also settles what happens before step 0, a later
+  // one goes on from the entry the call before left at its last group boundary
   __shared__ __attribute__ ((aligned (16))) uint8_t tab[256 * 128];
   uint32_t e = 0;
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && g_begin) e = q.entry[size_t (g_begin) * kD8Group];
+  if (threadIdx.x == 0 && !g_begin) {
     long long pos = search0;
     int npre = 0;
     if (q.pending < 0) { pre[1 + npre++] = q.pending; pos = q.pending + kD8Net; }
@@ -429,8 +433,8 @@ void d8_chain_resolve_kernel (const D8Params q, u64 trig_tail, long long search0
     e = uint32_t (min (pos, (long long) (kD8Net - 1)));
     q.entry[0] = uint8_t (e);
   }
-  const uint32_t ngroups = (q.nchunks + kD8Group - 1) / kD8Group;
-  for (uint32_t base = 0; base < ngroups; base += 256) {
+  const uint32_t ngroups = g_end;
+  for (uint32_t base = g_begin; base < ngroups; base += 256) {
     const uint32_t n = min (256u, ngroups - base);
     const uint4 *src = reinterpret_cast<const uint4 *> (group_tables (q) + size_t (base) * 128);
     for (uint32_t i = threadIdx.x; i < n * 8; i += 256) reinterpret_cast<uint4 *> (tab)[i] = src[i];
@@ -481,14 +485,14 @@ void d8_chain_exit_kernel (const D8Params q, int32_t *exit_of)
 // The parts' tables of the table kernel give the entry offset and the place in the list of every part by composition,
 // then one lane per part writes its openings.
 __global__ __launch_bounds__ (kD8WalkThreads)
-void d8_chain_walk_kernel (const D8Params q, const long long *pre, long long *pending_out)
+void d8_chain_walk_kernel (const D8Params q, const long long *pre, long long *pending_out, uint32_t c_begin)
 {
   __shared__ u64 bm[kD8ChunkSteps / 64];
   __shared__ __attribute__ ((aligned (16))) uint8_t sub_tab[2 * kD8Subs][128];
   uint8_t (*const sub_cnt)[128] = sub_tab + kD8Subs;
   __shared__ int s_entry[kD8Subs], s_off[kD8Subs], s_whole[kD8Subs], s_cut[kD8Subs];
   __shared__ __attribute__ ((aligned (16))) uint8_t before[(kD8Group - 1) * 128];      // the tables of the chunks of this group in front of this one
-  const uint32_t c = blockIdx.x;
+  const uint32_t c = c_begin + blockIdx.x;
   const uint32_t c_first = c / kD8Group * kD8Group;
   const long long n_lo = (long long) c * kD8ChunkSteps, n_hi = min (n_lo + (long long) kD8ChunkSteps, (long long) q.nsteps);
   const int nwords = int ((n_hi - n_lo + 63) >> 6);
@@ -875,17 +879,25 @@ hipError_t launch_d8_seed (uint32_t *announce, const uint32_t *addr, uint32_t n,
 
 // index just behind the last step that needs the running average (0 = none)
 __global__ __launch_bounds__ (256)
-void d8_last_amb_kernel (const uint64_t *amb, uint64_t nwords, unsigned long long *limit)
+void d8_last_amb_kernel (const uint64_t *amb, uint64_t w_begin, uint64_t w_end, unsigned long long *limit, uint32_t *flag_host)
 {
-  const uint64_t i = uint64_t (blockIdx.x) * 256 + threadIdx.x;
-  if (i >= nwords) return;
-  const uint64_t wv = amb[i];
-  if (wv) atomicMax (limit, (unsigned long long) (i * 64 + 64 - __builtin_clzll (wv)));
+  const uint64_t i = w_begin + uint64_t (blockIdx.x) * 256 + threadIdx.x;
+  if (i < w_end) {
+    const uint64_t wv = amb[i];
+    if (wv) {
+      const unsigned long long v = (unsigned long long) (i * 64 + 64 - __builtin_clzll (wv));
+      atomicMax (limit, v);
+      if (flag_host) *flag_host = 1u;                          // (pinned host memory: what the host looks at between two ranges)
+    }
+  }
 }
 
-hipError_t launch_d8_last_amb (const uint64_t *amb, uint64_t nwords, unsigned long long *limit, hipStream_t stream)
+// words [w_begin, w_end) of the plane; flag_host (may be null): a word in pinned host memory, cleared by the caller, set
+// when there is such a step
+hipError_t launch_d8_last_amb (const uint64_t *amb, uint64_t w_begin, uint64_t w_end, unsigned long long *limit, uint32_t *flag_host, hipStream_t stream)
 {
-  if (nwords) hipLaunchKernelGGL (d8_last_amb_kernel, dim3 ((unsigned) ((nwords + 255) / 256)), dim3 (256), 0, stream, amb, nwords, limit);
+  if (w_end > w_begin)
+    hipLaunchKernelGGL (d8_last_amb_kernel, dim3 ((unsigned) ((w_end - w_begin + 255) / 256)), dim3 (256), 0, stream, amb, w_begin, w_end, limit, flag_host);
   return hipGetLastError ();
 }
 
@@ -1033,19 +1045,26 @@ hipError_t upload_constants_8000 (const uint32_t *single_bit, const float *uc8_f
     default: return hipErrorInvalidValue;                                                                           \
   }
 
-// step_limit: only the strips that hold steps below it (0 = all)
-hipError_t launch_d8_trig (const D8Params &q, uint64_t step_limit, hipStream_t stream)
+// step_limit: only the strips that hold steps below it (0 = all); the steps of chunks [c_begin, c_begin + c_count) only
+// (c_count 0: to the end)
+hipError_t launch_d8_trig (const D8Params &q, uint64_t step_limit, hipStream_t stream, uint32_t c_begin, uint32_t c_count)
 {
   if (q.nsteps == 0) return hipSuccess;
+  static_assert (kD8ChunkSteps % (kD8StripSteps * kW8) == 0, "a chunk is whole workgroups of the trigger kernel");
   uint64_t nstrips = (q.nsteps + kD8StripSteps - 1) / kD8StripSteps;
+  const bool to_end = !c_count || uint64_t (c_begin) + c_count >= q.nchunks;
+  if (!to_end) nstrips = min (nstrips, (uint64_t (c_begin) + c_count) * (kD8ChunkSteps / kD8StripSteps));
   if (step_limit) nstrips = min (nstrips, (step_limit + kD8StripSteps - 1) / kD8StripSteps);
-  const dim3 grid ((unsigned) ((nstrips + kW8 - 1) / kW8)), block (64 * kW8);
-  if (q.write_arrays) { D8_DISPATCH (d8_trig_arrays_kernel, grid, block, q, nstrips); }
+  const uint32_t wg_begin = c_begin * uint32_t (kD8ChunkSteps / (kD8StripSteps * kW8));
+  const uint64_t wg_end = (nstrips + kW8 - 1) / kW8;
+  if (wg_end <= wg_begin) return hipSuccess;
+  const dim3 grid ((unsigned) (wg_end - wg_begin)), block (64 * kW8);
+  if (q.write_arrays) { D8_DISPATCH (d8_trig_arrays_kernel, grid, block, q, nstrips, wg_begin); }
   else {
-    D8_DISPATCH (d8_trig_kernel, grid, block, q, nstrips);
-    if (q.vmag && q.sp.conv != kConvMagU16 && !step_limit) {
+    D8_DISPATCH (d8_trig_kernel, grid, block, q, nstrips, wg_begin);
+    if (q.vmag && q.sp.conv != kConvMagU16 && !step_limit && to_end) {
       // the strips' own positions end at 2048 * (workgroups) - 536: the rest of [0, T) one by one
-      const long long own_end = 8ll * kD8StripSteps * kW8 * (long long) grid.x + 8 - kD8LookAhead;
+      const long long own_end = 8ll * kD8StripSteps * kW8 * (long long) wg_end + 8 - kD8LookAhead;
       const long long from = own_end > 0 ? own_end : 0, to = (long long) q.T;
       if (to > from) { D8_DISPATCH (d8_vmag_fill_kernel, dim3 ((unsigned) ((to - from + 255) / 256)), dim3 (256), q, from, to); }
     }
@@ -1059,9 +1078,11 @@ hipError_t launch_d8_acc (const D8Params &q, uint64_t limit, int32_t *acc_out, h
   return hipGetLastError ();
 }
 
-hipError_t launch_d8_chain_table (const D8Params &q, hipStream_t stream)
+// chunks [c_begin, c_begin + c_count) (c_count 0: to the end)
+hipError_t launch_d8_chain_table (const D8Params &q, hipStream_t stream, uint32_t c_begin, uint32_t c_count)
 {
-  if (q.nchunks) hipLaunchKernelGGL (d8_chain_table_kernel, dim3 (q.nchunks), dim3 (kD8ChainThreads), 0, stream, q);
+  const uint32_t n = c_count ? c_count : q.nchunks - c_begin;
+  if (n) hipLaunchKernelGGL (d8_chain_table_kernel, dim3 (n), dim3 (kD8ChainThreads), 0, stream, q, c_begin);
   return hipGetLastError ();
 }
 
@@ -1072,12 +1093,20 @@ hipError_t launch_d8_chain_exit (const D8Params &q, int32_t *exit_of, hipStream_
 }
 
 // behind launch_d8_chain_table
+// The chain through chunks [c_begin, c_begin + c_count) (c_count 0: to the end).  Ranges are taken in order, the first
+// from chunk 0: a range composes the groups of 64 chunks that end inside it (or with the stream), follows them from the
+// entry the range before left at its last group boundary, and walks its own chunks.
 hipError_t launch_d8_chain (const D8Params &q, unsigned long long trig_tail, long long search0, long long *pre,
-                            long long *pending_out, hipStream_t stream)
+                            long long *pending_out, hipStream_t stream, uint32_t c_begin, uint32_t c_count)
 {
-  if (q.nchunks) hipLaunchKernelGGL (d8_chain_group_kernel, dim3 ((q.nchunks + kD8Group - 1) / kD8Group), dim3 (128), 0, stream, q);
-  hipLaunchKernelGGL (d8_chain_resolve_kernel, dim3 (1), dim3 (256), 0, stream, q, (u64) trig_tail, search0, pre);
-  if (q.nchunks) hipLaunchKernelGGL (d8_chain_walk_kernel, dim3 (q.nchunks), dim3 (kD8WalkThreads), 0, stream, q, pre, pending_out);
+  const uint32_t c_end = c_count ? c_begin + c_count : q.nchunks;
+  const bool to_end = c_end >= q.nchunks;
+  const uint32_t g_begin = c_begin / kD8Group;                                          // groups before it are settled
+  const uint32_t g_end = to_end ? (q.nchunks + kD8Group - 1) / kD8Group : c_end / kD8Group;
+  if (g_end > g_begin) hipLaunchKernelGGL (d8_chain_group_kernel, dim3 (g_end - g_begin), dim3 (128), 0, stream, q, g_begin);
+  if (g_end > g_begin || !c_begin)
+    hipLaunchKernelGGL (d8_chain_resolve_kernel, dim3 (1), dim3 (256), 0, stream, q, (u64) trig_tail, search0, pre, g_begin, g_end > g_begin ? g_end : g_begin);
+  if (c_end > c_begin) hipLaunchKernelGGL (d8_chain_walk_kernel, dim3 (c_end - c_begin), dim3 (kD8WalkThreads), 0, stream, q, pre, pending_out, c_begin);
   return hipGetLastError ();
 }
 

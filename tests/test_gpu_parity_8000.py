@@ -114,6 +114,58 @@ def test_long_recording_runs_in_chunk_ranges():
         assert gst[k] == est[k], (k, gst[k], est[k])
 
 
+def test_planes_range_by_range_equal_planes_first(monkeypatch):
+    """Sixteen chunks and more: the trigger planes, the chain and the windows are formed range by range (the host walks
+    range r while the device forms the planes of range r + 2).  Ranges that are not whole groups of 64 chunks, three to
+    seven of them, against the run that forms all planes first -- and against the oracle."""
+    iq, _ = synth.capture(2_300_000, 8.0e6, "sc16", seed=95, frames_per_sec=2000, ap_fraction=0.25, n_icao=8)
+    iq = np.tile(iq, 4)                                           # 9.2 M samples: 17.5 chunks
+    exp, est = oracle_run(iq, "sc16", rate=8000000)
+    assert len(exp) > 1000
+    for ranges, plain in ((None, True), (None, False), (3, False), (5, False), (7, False), (17, False)):
+        if ranges is None:
+            monkeypatch.delenv("MODES_RANGES", raising=False)
+        else:
+            monkeypatch.setenv("MODES_RANGES", str(ranges))
+        if plain:
+            monkeypatch.setenv("MODES_D8_NO_PIPELINE", "1")
+        else:
+            monkeypatch.delenv("MODES_D8_NO_PIPELINE", raising=False)
+        e = da.Engine(8000000, da.INPUT_SC16)
+        e.run_host(iq)
+        assert_same_messages(e.messages(), exp)
+        for k in STAT_KEYS:
+            assert e.stats()[k] == est[k], (ranges, plain, k)
+        assert e.stats()["scan_retries"] == 0
+
+
+def test_quiet_stretch_in_a_later_range_ends_the_bet():
+    """Forming the planes range by range bets that no step behind the first range needs the running average.  A
+    near-silent stretch in the second half of a long recording loses it: the run starts again with all planes first
+    (stats.scan_retries says so) and the list is the oracle's."""
+    loud, _ = synth.capture(4_700_000, 8.0e6, "sc16", seed=96, frames_per_sec=2000, ap_fraction=0.2, n_icao=8)
+    quiet, _ = synth.capture(4_600_000, 8.0e6, "sc16", seed=97, frames_per_sec=1500, noise_sigma=0.0003,
+                             min_amp_db=-50, max_amp_db=-30, ap_fraction=0.2, n_icao=8)
+    iq = np.concatenate([loud, quiet])                            # 17.7 chunks, four ranges
+    exp, est = oracle_run(iq, "sc16", rate=8000000)
+    assert len(exp) > 500
+    e = da.Engine(8000000, da.INPUT_SC16)
+    e.run_host(iq)
+    assert e.stats()["scan_retries"] == 1
+    assert_same_messages(e.messages(), exp)
+    for k in STAT_KEYS:
+        assert e.stats()[k] == est[k], k
+    # the quiet stretch first: its steps are the first range's, the bet holds
+    iq2 = np.concatenate([quiet[: 2 * 2_000_000], loud, loud[: 2 * 2_500_000]])
+    exp2, est2 = oracle_run(iq2, "sc16", rate=8000000)
+    e2 = da.Engine(8000000, da.INPUT_SC16)
+    e2.run_host(iq2)
+    assert e2.stats()["scan_retries"] == 0
+    assert_same_messages(e2.messages(), exp2)
+    for k in STAT_KEYS:
+        assert e2.stats()[k] == est2[k], k
+
+
 def test_range_that_outgrows_its_pinned_share_is_gathered_again():
     """The packed windows / records of a range go straight to pinned host arrays sized from the last run (or a default
     per chunk); a range that does not fit is gathered again into arrays of its own size (MODES_D8_BUDGET: test hook)."""
