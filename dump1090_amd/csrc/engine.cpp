@@ -186,8 +186,9 @@ struct modes_engine {
   // what the host reads once per accept round, in one copy: 32 totals (u64), 64 `changed` words (one per round), the
   // ICAO cache behind the range's last block
   DevBuf<uint32_t> rb;
-  PinBuf<uint32_t> pin_rb;             // two landing areas: a round is queued while the one before is read
-  hipEvent_t round_ev[2] = { nullptr, nullptr };
+  PinBuf<uint32_t> pin_rb;             // where a range's totals and exit cache land, and the words the rounds report in
+  DevBuf<uint32_t> pass_words;         // [2][kPassWords]
+  hipEvent_t round_ev[2] = { nullptr, nullptr }, fin_ev = nullptr;
   // MODES_TIMING: device-side marks of a ranged decode (name, event), printed against the first scan's start
   std::vector<std::pair<std::string, hipEvent_t>> marks;
   bool marking = false;
@@ -673,6 +674,8 @@ static void mark (modes_engine *e, hipStream_t stream, const char *fmt, unsigned
 }
 
 constexpr uint32_t kRbTotals = 0, kRbChanged = 64, kRbRounds = 64, kRbMarked = kRbChanged + kRbRounds, kRbCache = kRbMarked + kRbRounds, kRbWords = kRbCache + kIcaoSlots;
+// per range parity, on the device: the rounds' `changed` and `marked` words and the ICAO cache behind the range
+constexpr uint32_t kPassWords = 2 * kRbRounds + kIcaoSlots;
 
 int reserve_accept_buffers (modes_engine *e, const ScanParams &sp)
 {
@@ -687,7 +690,9 @@ int reserve_accept_buffers (modes_engine *e, const ScanParams &sp)
   if ((rc = e->blk_stats.reserve (size_t (nblocks) * kBlkStats)) != MODES_OK) return rc;
   if ((rc = e->small_u32.reserve (2 * kIcaoSlots + 16)) != MODES_OK) return rc;
   if ((rc = e->rb.reserve (kRbWords)) != MODES_OK) return rc;
-  if ((rc = e->pin_rb.reserve (2 * kRbWords)) != MODES_OK) return rc;
+  if ((rc = e->pin_rb.reserve (kRbWords + 2 * kRbRounds)) != MODES_OK) return rc;       // the totals and the exit cache; the rounds' `marked` words of two ranges
+  if ((rc = e->pass_words.reserve (2 * kPassWords)) != MODES_OK) return rc;
+  if (!e->fin_ev) HIP_TRY (hipEventCreateWithFlags (&e->fin_ev, hipEventDisableTiming));
   if ((rc = e->pin_entry.reserve (kIcaoSlots)) != MODES_OK) return rc;
   if ((rc = e->dirty.reserve (nblocks)) != MODES_OK) return rc;
   if ((rc = e->blk_wrote.reserve (nblocks)) != MODES_OK) return rc;
@@ -698,32 +703,68 @@ int reserve_accept_buffers (modes_engine *e, const ScanParams &sp)
 }
 
 // The ordered accept pass on the device for one range of blocks whose scan is complete on `stream`: fixed-point rounds
-// over the per-block ICAO snapshots, then emit.  Enters with e->cache = the ICAO cache in front of the range and leaves
-// it as it stands behind the range; statistics add up in e->stats, the range's messages follow the e->pin_n already
-// there.  With `last` clear the read-back of the messages is left in flight on `stream`.
-int accept_range (modes_engine *e, const ScanParams &sp, uint64_t first_sample, hipStream_t stream, const RangeView &rg, bool last,
-                  hipStream_t copy_stream = nullptr, hipEvent_t emitted = nullptr)
+// over the per-block ICAO snapshots, then emit.  Three steps, so that a caller with several ranges can queue the next
+// range's rounds before it turns to this range's totals and messages:
+//   pass_begin   the range's entry cache (the host's, or what the range before left on the device), round 0
+//   pass_settle  the host follows the rounds until no block's entry cache changed
+//   pass_finish  totals, statistics, message offsets (on the emit stream: none of it stands between two rounds or
+//                between this range's rounds and the next's), then emit and read-back
+// A round on the pass's stream is the accept kernel and the three snapshot kernels, nothing else: the pass is a chain of
+// small dependent launches, and every launch in it is 5 us the ranges behind it wait for.
+struct PassState {
+  RangeView rg;
+  hipStream_t stream;
+  AcceptParams ap;
+  uint32_t par;                 // which of the two sets of round words / exit caches the range uses
+  uint32_t queued, rounds;
+  uint32_t *d_changed, *d_cache_out;
+  volatile uint32_t *marked_host;
+};
+
+int pass_queue_round (modes_engine *e, const ScanParams &sp, PassState &ps)
+{
+  (void) sp;
+  const uint32_t r = ps.queued, slot = r % kRbRounds;               // each round has its own `changed` word
+  const RangeView &rg = ps.rg;
+  if (r && slot == 0) {
+    HIP_TRY (launch_fill_u32 (ps.d_changed, 2 * kRbRounds, 0u, ps.stream));
+    for (uint32_t i = 0; i < kRbRounds; i++) ps.marked_host[i] = 0;     // (the host has seen every round queued so far: pass_settle)
+  }
+  ps.ap.changed = ps.d_changed + slot;
+  ps.ap.first_round = r == 0;
+  ps.ap.dirty = r ? e->dirty.p : nullptr;                          // from the second round on
+  HIP_TRY (launch_accept2400 (ps.ap, ps.stream));
+  HIP_TRY (launch_snapshots (e->delta.p + size_t (rg.blk0) * kIcaoSlots, e->blk_wrote.p + rg.blk0, rg.nblk, e->small_u32.p, e->chunk_last.p, e->chunk_entry.p,
+                             e->snap_in.p + size_t (rg.blk0) * kIcaoSlots, ps.d_cache_out, e->dirty.p + rg.blk0,
+                             ps.ap.changed, ps.d_changed + kRbRounds + slot, const_cast<uint32_t *> (ps.marked_host) + slot, ps.ap.first_round, ps.stream));
+  HIP_TRY (hipEventRecord (e->round_ev[r & 1], ps.stream));
+  mark (e, ps.stream, "  blocks %u..: round %u ends", rg.blk0, r);
+  ps.queued = r + 1;
+  return MODES_OK;
+}
+
+// prev: the range before this one, whose exit cache is on the device (null: the range starts from e->cache)
+int pass_begin (modes_engine *e, const ScanParams &sp, hipStream_t stream, const RangeView &rg, uint32_t par, const PassState *prev, PassState &ps)
 {
   const uint32_t B = e->block_samples;
-  const uint32_t nblocks = rg.nblk;
-  int rc;
-  uint32_t *d_cache_in = e->small_u32.p, *d_cache_out = e->rb.p + kRbCache, *d_changed = e->rb.p + kRbChanged;
-  uint32_t *snap_in = e->snap_in.p + size_t (rg.blk0) * kIcaoSlots, *delta = e->delta.p + size_t (rg.blk0) * kIcaoSlots;
-  uint32_t *acc_counts = e->acc_counts.p + rg.strip0, *dirty = e->dirty.p + rg.blk0, *blk_stats = e->blk_stats.p + size_t (rg.blk0) * kBlkStats;
-  uint64_t *d_totals = reinterpret_cast<uint64_t *> (e->rb.p + kRbTotals);
-
+  ps.rg = rg; ps.stream = stream; ps.par = par & 1; ps.queued = ps.rounds = 0;
+  ps.d_changed = e->pass_words.p + ps.par * kPassWords;
+  ps.d_cache_out = ps.d_changed + 2 * kRbRounds;
+  ps.marked_host = e->pin_rb.p + kRbWords + ps.par * kRbRounds;
+  uint32_t *d_cache_in = e->small_u32.p;
   mark (e, stream, "  blocks %u..: pass begins", rg.blk0);
-  // totals of the range's scan (candidates, valid preambles, overflowed strips)
-  HIP_TRY (launch_count_scan (e->counts.p + rg.strip0, e->vp_counts.p + rg.strip0, rg.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p, d_totals, stream));
   // (kernels, not blits: see launch_fill_u32)
-  memcpy (e->pin_entry.p, e->cache.raw (), kIcaoSlots * sizeof (uint32_t));
-  HIP_TRY (launch_copy_u32 (d_cache_in, e->pin_entry.p, kIcaoSlots, stream));
-  HIP_TRY (launch_fill_u32 (acc_counts, rg.nstrips, 0u, stream));
-  HIP_TRY (launch_fill_u32 (d_changed, 2 * kRbRounds, 0u, stream));
+  if (prev) HIP_TRY (launch_copy_u32 (d_cache_in, prev->d_cache_out, kIcaoSlots, stream));
+  else {
+    memcpy (e->pin_entry.p, e->cache.raw (), kIcaoSlots * sizeof (uint32_t));
+    HIP_TRY (launch_copy_u32 (d_cache_in, e->pin_entry.p, kIcaoSlots, stream));
+  }
+  HIP_TRY (launch_fill_u32 (e->acc_counts.p + rg.strip0, rg.nstrips, 0u, stream));
+  HIP_TRY (launch_fill_u32 (ps.d_changed, 2 * kRbRounds, 0u, stream));
+  for (uint32_t i = 0; i < kRbRounds; i++) ps.marked_host[i] = 0;
   // (no per-block state is prepared: in the first round every block starts from d_cache_in, writes its delta row only
   // if it wrote a slot, and says so in blk_wrote)
-
-  AcceptParams ap;
+  AcceptParams &ap = ps.ap;
   memset (&ap, 0, sizeof ap);
   ap.records = e->records.p; ap.counts = e->counts.p; ap.cap = e->cap; ap.nstrips = sp.nstrips;
   ap.strips_per_block = B / kStrip; ap.nblocks = uint32_t ((sp.nsamples + B - 1) / B); ap.nsamples = sp.nsamples; ap.block_samples = B;
@@ -732,50 +773,57 @@ int accept_range (modes_engine *e, const ScanParams &sp, uint64_t first_sample, 
   ap.vp_bitmap = e->mode == 2400 ? e->vp_bitmap.p : nullptr;
   ap.mode = e->mode;
   ap.cache_in = d_cache_in; ap.blk_wrote = e->blk_wrote.p; ap.first_round = 1;
-
-  // Every round queues what the last round needs behind it (snapshots, totals, the cache behind the range), so the round
-  // that finds nothing changed is already the complete result.  The host never stands between two rounds: round r + 1
-  // is queued before the host waits for what round r read back, so the device goes from round to round without the
-  // host's wake-up and launch latency in between (about 0.1 ms a round); the one round queued too many -- behind the
-  // round that found nothing changed -- looks at no block (none is dirty) and leaves every result as it is.
-  auto queue_round = [&] (uint32_t r) -> int {
-    const uint32_t slot = r % kRbRounds;                          // each round has its own `changed` word
-    if (r && slot == 0) HIP_TRY (launch_fill_u32 (d_changed, 2 * kRbRounds, 0u, stream));
-    ap.changed = d_changed + slot;
-    ap.first_round = r == 0;
-    ap.dirty = r ? e->dirty.p : nullptr;                          // from the second round on
-    HIP_TRY (launch_accept2400 (ap, stream));
-    HIP_TRY (launch_snapshots (delta, e->blk_wrote.p + rg.blk0, nblocks, d_cache_in, e->chunk_last.p, e->chunk_entry.p, snap_in, d_cache_out, dirty,
-                               ap.changed, d_changed + kRbRounds + slot, ap.first_round, stream));
-    // totals of accepted messages and the block statistics, read back together with the scan's totals
-    HIP_TRY (launch_count_scan (acc_counts, e->vp_counts.p + rg.strip0, rg.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p, d_totals + 4, stream));
-    HIP_TRY (launch_blk_stats_sum (blk_stats, nblocks, reinterpret_cast<unsigned long long *> (d_totals + 8), stream));
-    // where each strip's messages go, should this round be the last (from the chunk sums just formed; a list per round
-    // parity: the round queued behind the last one writes the other list while the emit reads this one)
-    HIP_TRY (launch_strip_offsets (acc_counts, rg.nstrips, e->chunk_sum.p, e->offsets.p + size_t (r & 1) * sp.nstrips + rg.strip0, stream));
-    HIP_TRY (launch_copy_u32 (e->pin_rb.p + (r & 1) * kRbWords, e->rb.p, kRbWords, stream));          // into pinned host memory
-    HIP_TRY (hipEventRecord (e->round_ev[r & 1], stream));
-    mark (e, stream, "  blocks %u..: round %u ends", rg.blk0, r);
-    return MODES_OK;
-  };
   if (!e->round_ev[0]) for (hipEvent_t &ev : e->round_ev) HIP_TRY (hipEventCreateWithFlags (&ev, hipEventDisableTiming));
-  uint32_t rounds = 0;
-  if ((rc = queue_round (0)) != MODES_OK) return rc;
-  const uint32_t *rbh = nullptr;
+  return pass_queue_round (e, sp, ps);
+}
+
+// The host never stands between two rounds: round r + 1 is queued before the host waits for what round r found, so the
+// device goes from round to round without the host's wake-up and launch latency in between (about 0.1 ms a round); the
+// one round queued too many -- behind the round that found nothing changed -- looks at no block (none is dirty) and
+// leaves every result as it is.
+int pass_settle (modes_engine *e, const ScanParams &sp, PassState &ps)
+{
+  int rc;
   for (;;) {
     // (a round that wraps the `changed` words clears them first: not while the round before may still set its own)
-    const bool ahead = (rounds + 1) % kRbRounds != 0;
-    if (ahead && (rc = queue_round (rounds + 1)) != MODES_OK) return rc;
-    HIP_TRY (hipEventSynchronize (e->round_ev[rounds & 1]));
-    rbh = e->pin_rb.p + (rounds & 1) * kRbWords;
-    const bool changed = rbh[kRbMarked + rounds % kRbRounds] != 0;        // a block has to run again
-    rounds++;
+    const bool ahead = (ps.rounds + 1) % kRbRounds != 0;
+    if (ahead && ps.queued < ps.rounds + 2 && (rc = pass_queue_round (e, sp, ps)) != MODES_OK) return rc;
+    HIP_TRY (hipEventSynchronize (e->round_ev[ps.rounds & 1]));
+    const bool changed = ps.marked_host[ps.rounds % kRbRounds] != 0;      // a block has to run again
+    ps.rounds++;
     if (!changed) break;
     // a write set can only change because an earlier block's did: block k is final after round k + 1 at the latest
-    if (rounds > nblocks + 2) return fail (MODES_E_HIP, "accept pass did not reach its fixed point in %u rounds", rounds);
-    if (!ahead && (rc = queue_round (rounds)) != MODES_OK) return rc;
+    if (ps.rounds > ps.rg.nblk + 2) return fail (MODES_E_HIP, "accept pass did not reach its fixed point in %u rounds", ps.rounds);
+    if (ps.queued < ps.rounds + 1 && (rc = pass_queue_round (e, sp, ps)) != MODES_OK) return rc;
   }
-  e->stats.replay_rounds += rounds;
+  e->stats.replay_rounds += ps.rounds;
+  return MODES_OK;
+}
+
+// fin: the stream the totals, the emit kernel (and, without a copy stream, the read-back) run on; with streams of their
+// own the emit and the read-back leave the pass's stream as soon as the round that settled the range has ended (not the
+// round queued behind it): pass, emit and read-back of consecutive ranges form a pipeline of three stages beside the scan.
+// settled_ev: recorded behind the settled round (taken when the range settled, before the next range's rounds reuse the
+// round events).
+int pass_finish (modes_engine *e, const ScanParams &sp, uint64_t first_sample, PassState &ps, bool last, hipStream_t fin,
+                 hipStream_t copy_stream, hipEvent_t emitted)
+{
+  const RangeView &rg = ps.rg;
+  int rc;
+  uint32_t *acc_counts = e->acc_counts.p + rg.strip0;
+  uint64_t *d_totals = reinterpret_cast<uint64_t *> (e->rb.p + kRbTotals);
+  const uint32_t rounds = ps.rounds;
+  // totals of the range's scan (candidates, valid preambles, overflowed strips), of the accepted messages, the block
+  // statistics, and where each strip's messages go
+  HIP_TRY (launch_count_scan (e->counts.p + rg.strip0, e->vp_counts.p + rg.strip0, rg.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p, d_totals, fin));
+  HIP_TRY (launch_count_scan (acc_counts, e->vp_counts.p + rg.strip0, rg.nstrips, e->chunk_sum.p, e->chunk_vp.p, e->chunk_ovf.p, d_totals + 4, fin));
+  HIP_TRY (launch_blk_stats_sum (e->blk_stats.p + size_t (rg.blk0) * kBlkStats, rg.nblk, reinterpret_cast<unsigned long long *> (d_totals + 8), fin));
+  HIP_TRY (launch_strip_offsets (acc_counts, rg.nstrips, e->chunk_sum.p, e->offsets.p + rg.strip0, fin));
+  HIP_TRY (launch_copy_u32 (e->pin_rb.p, e->rb.p, kRbChanged, fin));                                  // into pinned host memory
+  HIP_TRY (launch_copy_u32 (e->pin_rb.p + kRbCache, ps.d_cache_out, kIcaoSlots, fin));
+  HIP_TRY (hipEventRecord (e->fin_ev, fin));
+  HIP_TRY (hipEventSynchronize (e->fin_ev));
+  const uint32_t *rbh = e->pin_rb.p;
   memcpy (e->cache.raw (), rbh + kRbCache, kIcaoSlots * sizeof (uint32_t));
   const unsigned long long *st = reinterpret_cast<const unsigned long long *> (rbh + kRbTotals), *tot = st + 4, *sum = st + 8;
   if (st[2]) return fail (MODES_E_OVERFLOW, "%llu strips overflowed their candidate slots (cap %u)", st[2], e->cap);
@@ -791,22 +839,23 @@ int accept_range (modes_engine *e, const ScanParams &sp, uint64_t first_sample, 
   if (e->mode == 2000) e->stats.valid_preamble += sum[kStVp];     // every valid preamble is a record there
   else e->stats.valid_preamble += st[1] - sum[kStSkippedVp];
   if (sum[kStAccepted] != nm) return fail (MODES_E_HIP, "accepted-count mismatch (%llu vs %zu)", (unsigned long long) sum[kStAccepted], nm);
+  (void) rounds;
 
   const size_t base = e->pin_n;
   if (nm) {
     if (base + nm > e->d_messages.cap || base + nm > e->pin_cap) {
       // the list outgrew what the run set out with: wait for the read-backs in flight, then move to larger buffers
       if (base) {
-        if (copy_stream) HIP_TRY (hipStreamSynchronize (e->emit_stream));
-        HIP_TRY (hipStreamSynchronize (copy_stream ? copy_stream : stream));
+        HIP_TRY (hipStreamSynchronize (fin));
+        if (copy_stream) HIP_TRY (hipStreamSynchronize (copy_stream));
       }
-      const uint32_t nb_all = ap.nblocks, nb_done = rg.blk0 + rg.nblk;
+      const uint32_t nb_all = ps.ap.nblocks, nb_done = rg.blk0 + rg.nblk;
       const size_t guess = size_t (double (base + nm) * double (nb_all) / double (nb_done) * 1.25) + 1024;
       if ((rc = reserve_messages (e, guess, base)) != MODES_OK) return rc;
     }
     EmitParams ep;
     memset (&ep, 0, sizeof ep);
-    ep.records = e->records.p; ep.counts = e->counts.p; ep.acc_counts = e->acc_counts.p; ep.offsets = e->offsets.p + size_t ((rounds - 1) & 1) * sp.nstrips;
+    ep.records = e->records.p; ep.counts = e->counts.p; ep.acc_counts = e->acc_counts.p; ep.offsets = e->offsets.p;
     ep.cap = e->cap; ep.nstrips = sp.nstrips;
     ep.iq = sp.iq; ep.nsamples = sp.nsamples; ep.navail = sp.navail; ep.halo = sp.halo; ep.ov = sp.ov;
     ep.block_samples = sp.block_samples; ep.conv = sp.conv; ep.lut256 = sp.lut256;
@@ -814,29 +863,38 @@ int accept_range (modes_engine *e, const ScanParams &sp, uint64_t first_sample, 
     ep.messages = e->d_messages.p + base;             // offsets[] count from the range's first strip
     ep.mode = e->mode;
     ep.strip_begin = rg.strip0; ep.strip_end = rg.strip0 + rg.nstrips;
-    // With streams of their own the emit and the read-back leave the pass's stream as soon as the round that settled
-    // the range has ended (not the round queued behind it): pass, emit and read-back of consecutive ranges form a
-    // pipeline of three stages beside the scan.
-    hipStream_t cs = stream;
+    mark (e, fin, "  blocks %u..: emit begins", rg.blk0);
+    HIP_TRY (launch_emit2400 (ep, fin));
+    mark (e, fin, "  blocks %u..: emit ends", rg.blk0);
+    hipStream_t cs = fin;
     if (copy_stream) {
-      HIP_TRY (hipStreamWaitEvent (e->emit_stream, e->round_ev[(rounds - 1) & 1], 0));
-      mark (e, e->emit_stream, "  blocks %u..: emit begins", rg.blk0);
-      HIP_TRY (launch_emit2400 (ep, e->emit_stream));
-      HIP_TRY (hipEventRecord (emitted, e->emit_stream));
-      mark (e, e->emit_stream, "  blocks %u..: emit ends", rg.blk0);
+      HIP_TRY (hipEventRecord (emitted, fin));
       HIP_TRY (hipStreamWaitEvent (copy_stream, emitted, 0));
       cs = copy_stream;
-    } else HIP_TRY (launch_emit2400 (ep, stream));
+    }
     HIP_TRY (hipMemcpyAsync (e->pin_msgs + base, e->d_messages.p + base, nm * sizeof (modes_message), hipMemcpyDeviceToHost, cs));
     mark (e, cs, "  blocks %u..: read-back ends", rg.blk0);
     e->pin_n = base + nm;
   }
   e->in_pinned = true;
   if (last) {
-    HIP_TRY (hipStreamSynchronize (stream));
-    if (copy_stream) { HIP_TRY (hipStreamSynchronize (e->emit_stream)); HIP_TRY (hipStreamSynchronize (copy_stream)); }
+    HIP_TRY (hipStreamSynchronize (ps.stream));
+    HIP_TRY (hipStreamSynchronize (fin));
+    if (copy_stream) HIP_TRY (hipStreamSynchronize (copy_stream));
   }
   return MODES_OK;
+}
+
+// one range, begin to finish, everything on `stream`: enters with e->cache = the ICAO cache in front of the range and
+// leaves it as it stands behind the range; statistics add up in e->stats, the range's messages follow the e->pin_n
+// already there
+int accept_range (modes_engine *e, const ScanParams &sp, uint64_t first_sample, hipStream_t stream, const RangeView &rg, bool last)
+{
+  PassState ps;
+  int rc = pass_begin (e, sp, stream, rg, 0, nullptr, ps);
+  if (rc == MODES_OK) rc = pass_settle (e, sp, ps);
+  if (rc == MODES_OK) rc = pass_finish (e, sp, first_sample, ps, last, stream, nullptr, nullptr);
+  return rc;
 }
 
 // The whole shard as one range, behind a scan already queued on `stream`.
@@ -920,13 +978,24 @@ int scan_and_accept_in_ranges (modes_engine *e, ScanParams &sp, uint64_t first_s
   e->marking = timing;
   const auto t_start = std::chrono::steady_clock::now ();
   auto since = [&] { return std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now () - t_start).count (); };
+  // the next range's rounds are queued as soon as this range has settled, before the host turns to this range's totals
+  // and messages: the pass's stream goes from range to range without waiting for the host's dealings with the emit stream
+  PassState pass[2];
+  HIP_TRY (hipStreamWaitEvent (e->post_stream, e->range_events[1], 0));
+  if ((rc = pass_begin (e, sp, e->post_stream, rgs[0], 0, nullptr, pass[0])) != MODES_OK) return rc;
   for (uint32_t r = 0; r < nranges; r++) {
-    HIP_TRY (hipStreamWaitEvent (e->post_stream, e->range_events[2 * r + 1], 0));
-    const uint64_t rounds_before = e->stats.replay_rounds;
+    PassState &ps = pass[r & 1];
     const double t_in = since ();
-    if ((rc = accept_range (e, sp, first_sample, e->post_stream, rgs[r], r + 1 == nranges, e->copy_stream, e->emit_events[r])) != MODES_OK) return rc;
-    if (timing) fprintf (stderr, "  range %u (%u blocks): pass queued at %.3f ms, settled (%llu rounds)%s at %.3f ms, %zu messages so far\n", r, rgs[r].nblk, t_in,
-                         (unsigned long long) (e->stats.replay_rounds - rounds_before), r + 1 == nranges ? " and everything read back" : "", since (), e->pin_n);
+    if ((rc = pass_settle (e, sp, ps)) != MODES_OK) return rc;
+    const double t_settled = since ();
+    HIP_TRY (hipStreamWaitEvent (e->emit_stream, e->round_ev[(ps.rounds - 1) & 1], 0));       // (before the next range's rounds record the event again)
+    if (r + 1 < nranges) {
+      HIP_TRY (hipStreamWaitEvent (e->post_stream, e->range_events[2 * (r + 1) + 1], 0));
+      if ((rc = pass_begin (e, sp, e->post_stream, rgs[r + 1], r + 1, &ps, pass[(r + 1) & 1])) != MODES_OK) return rc;
+    }
+    if ((rc = pass_finish (e, sp, first_sample, ps, r + 1 == nranges, e->emit_stream, e->copy_stream, e->emit_events[r])) != MODES_OK) return rc;
+    if (timing) fprintf (stderr, "  range %u (%u blocks): host turned to it at %.3f ms, settled (%u rounds) at %.3f ms, messages queued%s at %.3f ms, %zu messages so far\n", r, rgs[r].nblk, t_in,
+                         ps.rounds, t_settled, r + 1 == nranges ? " and everything read back" : "", since (), e->pin_n);
   }
   HIP_TRY (hipStreamSynchronize (stream));
   if (timing) {
@@ -1016,11 +1085,12 @@ void modes_engine_destroy (modes_engine *e)
   for (hipEvent_t ev : e->dc_ev) if (ev) (void) hipEventDestroy (ev);
   if (e->dc_power_done) (void) hipEventDestroy (e->dc_power_done);
   for (hipEvent_t ev : e->round_ev) if (ev) (void) hipEventDestroy (ev);
+  if (e->fin_ev) (void) hipEventDestroy (e->fin_ev);
   e->dc_mag.release (); e->dc_sq.release (); e->dc_desc.release (); e->dc_zs.release (); e->dc_ze.release (); e->dc_unm.release ();
   e->d8_trig.release (); e->d8_amb.release (); e->d8_off.release (); e->d8_p0.release (); e->d8_mx.release ();
   e->d8_win_count.release (); e->d8_chunk_rec.release (); e->d8_announce.release (); e->d8_table.release (); e->d8_entry.release ();
   e->d8_win_start.release (); e->d8_small.release (); e->d8_windows.release (); e->d8_win_packed.release ();
-  e->d8_records.release (); e->d8_rec_packed.release (); e->dirty.release (); e->blk_wrote.release (); e->rb.release (); e->pin_rb.release (); e->pin_entry.release (); e->pin_sums.release (); e->pin_tot.release (); e->d8_tot.release (); e->pin_wins2.release (); e->pin_recs2.release (); e->pin_rpos.release (); e->pin_rlen.release ();
+  e->d8_records.release (); e->d8_rec_packed.release (); e->dirty.release (); e->blk_wrote.release (); e->rb.release (); e->pass_words.release (); e->pin_rb.release (); e->pin_entry.release (); e->pin_sums.release (); e->pin_tot.release (); e->d8_tot.release (); e->pin_wins2.release (); e->pin_recs2.release (); e->pin_rpos.release (); e->pin_rlen.release ();
   e->d8_dprev.release (); e->d8_dnext.release (); e->pin_d8.release (); e->d8_exit_of.release ();
   e->d_fields.release (); e->pin_fields.release ();
   if (e->post_stream) (void) hipStreamDestroy (e->post_stream);

@@ -53,7 +53,7 @@ hipError_t launch_dc_linear (int conv, const uint8_t *iq, uint64_t n, double A, 
 hipError_t launch_accept2400 (const AcceptParams &p, hipStream_t stream);
 hipError_t launch_snapshots (const uint32_t *delta, const uint32_t *blk_wrote, uint32_t nblocks, const uint32_t *cache_in, uint32_t *chunk_last,
                              uint32_t *chunk_entry, uint32_t *snap_in, uint32_t *cache_out, uint32_t *dirty, const uint32_t *changed, uint32_t *marked,
-                             int first_round, hipStream_t stream);
+                             uint32_t *marked_host, int first_round, hipStream_t stream);      // marked_host (may be null): `marked` again, in pinned host memory
 hipError_t launch_emit2400 (const EmitParams &p, hipStream_t stream);
 hipError_t launch_strip_offsets (const uint32_t *acc_counts, uint32_t nstrips, const uint64_t *chunk_sum, uint64_t *offsets, hipStream_t stream);
 hipError_t launch_fill_u32 (uint32_t *p, size_t n, uint32_t v, hipStream_t stream);

@@ -1095,7 +1095,7 @@ void snap_chunk_scan_kernel (const uint32_t *chunk_last, uint32_t nchunks, const
 
 __global__ __launch_bounds__ (256)
 void snap_fill_kernel (const uint32_t *delta, const uint32_t *blk_wrote, uint32_t nblocks, const uint32_t *chunk_entry, uint32_t *snap_in,
-                       uint32_t *dirty, const uint32_t *changed, const uint32_t *cache_in, int first_round, uint32_t *marked)
+                       uint32_t *dirty, const uint32_t *changed, const uint32_t *cache_in, int first_round, uint32_t *marked, uint32_t *marked_host)
 {
   if (!*changed) return;
   const uint32_t s = blockIdx.x * 256 + threadIdx.x, chunk = blockIdx.y;
@@ -1116,7 +1116,8 @@ void snap_fill_kernel (const uint32_t *delta, const uint32_t *blk_wrote, uint32_
   }
   // Deltas can change without any block's entry cache changing (a slot written again with what it held): then no block
   // is marked, the round just run was already the last one, and `marked` stays clear to say so.
-  if (__ballot (any) && (threadIdx.x & 63) == 0) atomicOr (marked, 1u);
+  // (marked_host: the same word in pinned host memory, where the host looks when the round's event has fired)
+  if (__ballot (any) && (threadIdx.x & 63) == 0) { atomicOr (marked, 1u); if (marked_host) *marked_host = 1u; }
 }
 
 // sums of the per-block statistics: out[k] = sum over blocks of blk_stats[block][k]
@@ -1654,13 +1655,13 @@ hipError_t launch_accept2400 (const AcceptParams &p, hipStream_t stream)
 // delta -> snap_in for the next round; chunk_last/chunk_entry hold (nblocks/32 + 1) * 1024 words each
 hipError_t launch_snapshots (const uint32_t *delta, const uint32_t *blk_wrote, uint32_t nblocks, const uint32_t *cache_in, uint32_t *chunk_last,
                              uint32_t *chunk_entry, uint32_t *snap_in, uint32_t *cache_out, uint32_t *dirty, const uint32_t *changed,
-                             uint32_t *marked, int first_round, hipStream_t stream)
+                             uint32_t *marked, uint32_t *marked_host, int first_round, hipStream_t stream)
 {
   if (nblocks == 0) return hipSuccess;
   const uint32_t nchunks = (nblocks + kSnapChunk - 1) / kSnapChunk;
   hipLaunchKernelGGL (snap_chunk_last_kernel, dim3 (kIcaoSlots / 256, nchunks), dim3 (256), 0, stream, delta, blk_wrote, nblocks, chunk_last, dirty, changed);
   hipLaunchKernelGGL (snap_chunk_scan_kernel, dim3 (kIcaoSlots / 256), dim3 (256), 0, stream, chunk_last, nchunks, cache_in, chunk_entry, cache_out, changed, first_round);
-  hipLaunchKernelGGL (snap_fill_kernel, dim3 (kIcaoSlots / 256, nchunks), dim3 (256), 0, stream, delta, blk_wrote, nblocks, chunk_entry, snap_in, dirty, changed, cache_in, first_round, marked);
+  hipLaunchKernelGGL (snap_fill_kernel, dim3 (kIcaoSlots / 256, nchunks), dim3 (256), 0, stream, delta, blk_wrote, nblocks, chunk_entry, snap_in, dirty, changed, cache_in, first_round, marked, marked_host);
   return hipGetLastError ();
 }
 
