@@ -252,3 +252,30 @@ def test_torch_group_over_rccl_single_rank():
         assert_same_messages(msgs, exp)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("rate", [2400000, 2000000, 8000000])
+def test_shard_deep_in_a_long_stream(rate):
+    """Rank 7 of 8 x 4 GiB starts 15 G samples into the stream: positions and timestamps beyond 2^32 samples.  The same
+    shard decoded at stream sample F and at F + 2^34 (whole blocks) gives the same list, every timestamp moved on by
+    2^34 samples' worth of the 12 MHz clock."""
+    B = 65536
+    iq, _ = synth.capture(B * 6 + 777, float(rate), "sc16", seed=99, frames_per_sec=2500, ap_fraction=0.3, n_icao=6)
+    d = torch.from_numpy(iq.view(np.int16)).to("cuda:0")
+    first, count = 2 * B, len(iq) // 2 - 2 * B
+    shift = 1 << 34
+    lists = []
+    for off in (0, shift):
+        e = da.Engine(rate, da.INPUT_SC16, fix_bits=1)
+        e.run_device(d.data_ptr(), 4 * first)                 # the stream in front of the shard: cache, halo, 8 MS/s state
+        halo = e.tail_halo()
+        if rate == 8000000:
+            e.set_d8_state(e.get_d8_state(want_acc=True))
+        e.run_device(d.data_ptr() + 4 * first, 4 * count, first_sample=first + off, halo_ptr=halo)
+        lists.append(e.messages().copy())
+    a, b = lists
+    assert len(a) > 50 and len(a) == len(b)
+    ticks = shift * 12000000 // rate
+    assert np.array_equal(b["timestamp"].astype(np.uint64), a["timestamp"].astype(np.uint64) + np.uint64(ticks))
+    for k in ("msg", "msg_bits", "msg_type", "addr", "crc", "error_bits", "sig_level"):
+        assert np.array_equal(a[k], b[k]), k
