@@ -179,3 +179,39 @@ def test_full_size_dc_stream_in_two_calls_equals_one():
     b = e2.messages().copy()
     assert shard.merge([a, b]).tobytes() == whole.tobytes()
     assert e2.get_dc_state() == z_whole
+
+
+@pytest.mark.parametrize("name,rate,fmt", [("uc8_2400_lut", 2400000, "uc8lut"), ("sc16_8000", 8000000, "sc16")])
+def test_last_shard_of_eight_ranks(name, rate, fmt):
+    """What rank 7 of `bench.py --gpus 8` holds: the last eighth of ONE recording of 8 x 4 GiB, generated on its own and
+    decoded at its place in the stream, 15 G (uc8) / 7.5 G (sc16) samples in.  The strong injected frames of that
+    eighth come back with their bytes at their stream times, every message passes its parity, the list is in order."""
+    bps = 2 if fmt == "uc8lut" else 4
+    world, rank = 8, 7
+    n = int(GIB * (1 << 30)) // bps
+    B = 262144 // bps
+    first, count = shard.plan_shards(world * n, B, world)[rank]
+    chunk = 1 << 24
+    g0 = first // chunk * chunk
+    d, info = synth_torch.capture_gpu(world * n, float(rate), fmt, seed=1, device="cuda:0", chunk=chunk,
+                                      sample_range=(g0, -(-(first + count) // chunk) * chunk),
+                                      frames_per_sec=3000.0 if rate != 8000000 else 1000.0)
+    torch.cuda.synchronize()
+    sel = (info["pos"] >= first) & (info["pos"] < first + count)
+    info = dict(info, pos=info["pos"][sel], which=info["which"][sel], amp=info["amp"][sel])
+    e = da.Engine(rate, da.INPUT_UC8 if fmt == "uc8lut" else da.INPUT_SC16)
+    if rate == 8000000:
+        # the state a shard behind the first is entered with: here that of a stream that was silent so far
+        quiet = torch.zeros(2 * 65536, dtype=torch.int16, device="cuda:0")
+        e.run_device(quiet.data_ptr(), quiet.numel() * 2)
+        e.set_d8_state(e.get_d8_state(want_acc=True))
+    e.run_device(d.data_ptr() + bps * (first - g0), bps * count, first_sample=first)
+    m = e.messages().copy()
+    assert len(m) > 5000
+    assert int(m["timestamp"].min()) >= int(first * 12e6 / rate) - 2400
+    check_parity_of_every_message(m)
+    check_stream_order(m, strict=rate != 8000000)
+    # (positions count from the start of the whole recording; the first frames of the shard, whose neighbours in front
+    # of it are not in the list, are left out)
+    keep = info["pos"] > first + 4000
+    check_injected_frames_come_back(m, dict(info, pos=info["pos"][keep], which=info["which"][keep], amp=info["amp"][keep]), rate, first + count)
