@@ -217,13 +217,15 @@ struct D8Params {
 #define DC_BATCH 4096
 #endif
 constexpr int kDcBatch = DC_BATCH;     // samples a workgroup stages per round: sixteen per thread
+constexpr int kDcCkpt = 4 * kDcBatch; // samples between two checkpoints of a chunk's chains (DcParams::ckpt)
 constexpr int kDcSeg = 65536;          // samples per segment of the real-arithmetic estimate (dc_linear_kernel)
 struct DcChunk {
   long long start;                     // first sample the chain steps (<= the chunk's first sample)
   float zIlo, zIhi, zQlo, zQhi;        // bracket in front of `start`
   uint32_t chunk;                      // which chunk of the shard
   uint32_t slot;                       // where the results of this chain go (z_start, z_end, unmerged, closed_at, z_close)
-  long long stop;                      // sample to stop in front of (a multiple of kDcBatch inside the chunk), or <= 0: the chunk's end
+  long long stop;                      // sample to stop in front of (a multiple of kDcBatch inside the chunk); 0: the chunk's end;
+                                       // -1: the chunk's end, or the first checkpoint where the chain has met the first pass's (DcParams::ckpt)
 };
 static_assert(sizeof(DcChunk) == 40, "DcChunk must be 40 bytes");
 
@@ -240,6 +242,8 @@ struct DcParams {
   uint32_t       *unmerged;    // [slots] 1 = the bracket was still open at the chunk's first sample
   long long      *closed_at;   // [slots] first batch of the chunk in front of which both brackets were closed (-1: never)
   float          *z_close;     // [slots][2] z1_I, z1_Q in front of that batch
+  float          *ckpt;        // [chunks][nck][2] z1_I, z1_Q of the first pass in front of every kDcCkpt-th sample of a chunk
+  uint32_t        nck;
   unsigned long long *ticks;   // [nchunks][16] profiling aid (wave 0: lifetime in clock ticks, guess rounds, plain rounds, ticks in the chain, at barriers); may be null
   unsigned long long *rounds;  // [2] guess rounds (256 samples tried), plain rounds (64 samples stepped one by one); may be null
 };

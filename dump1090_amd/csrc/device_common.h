@@ -67,14 +67,25 @@ __device__ __forceinline__ uint32_t mag_sc16_pair (uint32_t d0, uint32_t d1)
   return __builtin_amdgcn_perm (mag_sc16_sum (d1), mag_sc16_sum (d0), 0x07060302u);
 }
 
-// ref: src/convert.c:142-147 -- the tail shared by the three float converters, DC block already applied
+// ref: src/convert.c:142-147 -- the tail shared by the three float converters, DC block already applied.
+// sqrtf as the compiler lowers it carries the scaling that keeps v_sqrt_f32 exact for denormal inputs and a class test
+// for 0 / inf: seventeen operations.  Here mag_sq lies in [0, 1], and below 2^-40 the magnitude is 0 whatever the
+// root's last bit is (65535 * 2^-20 + 0.5 < 1), so the correctly rounded root is only needed for normal inputs: the
+// hardware's root (1 ulp) and the two residual tests around it, the same correction the compiler emits.  The product
+// 65535 * root is exact in double and the sum rounds nowhere near an integer, so one fused operation gives the
+// reference's `root * 65535.0 + 0.5`.
 __device__ __forceinline__ uint16_t mag_from_float (float fI, float fQ, float *mag_sq_out)
 {
   float mag_sq = __fadd_rn (__fmul_rn (fI, fI), __fmul_rn (fQ, fQ));
-  if (mag_sq > 1.0f) mag_sq = 1.0f;
+  mag_sq = __builtin_fminf (mag_sq, 1.0f);                        // (never NaN: the inputs are finite)
   if (mag_sq_out) *mag_sq_out = mag_sq;
-  const double v = __dadd_rn (__dmul_rn (double (sqrtf (mag_sq)), 65535.0), 0.5);
-  return uint16_t (int (v));
+  float r = __builtin_amdgcn_sqrtf (mag_sq);
+  const float rm = __uint_as_float (__float_as_uint (r) - 1u), rp = __uint_as_float (__float_as_uint (r) + 1u);
+  const float em = __builtin_fmaf (-rm, r, mag_sq), ep = __builtin_fmaf (-rp, r, mag_sq);
+  r = em <= 0.0f ? rm : r;
+  r = ep > 0.0f ? rp : r;
+  const double v = __builtin_fma (double (r), 65535.0, 0.5);
+  return mag_sq < 0x1p-40f ? uint16_t (0) : uint16_t (int (v));
 }
 
 // ------------------------------------------------------------------------------------------

@@ -236,7 +236,7 @@ struct modes_engine {
   DevBuf<float> dc_zs, dc_ze;
   DevBuf<uint32_t> dc_unm;
   DevBuf<double> dc_lin;
-  DevBuf<float> dc_zc;
+  DevBuf<float> dc_zc, dc_ckpt;
   DevBuf<long long> dc_closed;
   DevBuf<unsigned long long> dc_ticks;
   hipEvent_t dc_power_done = nullptr;        // the block powers of a filter_dc run are formed beside the scan
@@ -464,6 +464,13 @@ int prepare_dc (modes_engine *e, const void *d_iq, size_t nbytes, const uint16_t
   auto lo_of = [&] (uint64_t j, int ch) { const float v = float (est[2 * j + ch] - half[2 * j + ch]); return std::max (-bound, std::nextafterf (v, -INFINITY)); };
   auto hi_of = [&] (uint64_t j, int ch) { const float v = float (est[2 * j + ch] + half[2 * j + ch]); return std::min (bound, std::nextafterf (v, INFINITY)); };
 
+  auto mid_of = [&] (uint64_t j, int ch) { return std::min (bound, std::max (-bound, float (est[2 * j + ch]))); };
+  auto same = [] (float a, float b) { return memcmp (&a, &b, sizeof a) == 0; };
+
+  // Every chunk but the first starts ONE chain per channel where the filter is in real arithmetic, `warm` samples early;
+  // it is right when it enters the chunk with the very state the chunk before ended on (checked below).  The first
+  // chunk starts from the stream's own state, or -- behind a lead-in, where nothing earlier can vouch for it -- from a
+  // bracket that must have closed by the shard's first sample.
   std::vector<DcChunk> desc (K);
   for (uint64_t c = 0; c < K; c++) {
     DcChunk &d = desc[c];
@@ -473,15 +480,18 @@ int prepare_dc (modes_engine *e, const void *d_iq, size_t nbytes, const uint16_t
     if (c0 + lead_eff > warm) j = (c0 + lead_eff - warm) / kDcSeg;
     d.start = (long long) (j * kDcSeg) - (long long) lead_eff;
     if (j == 0 && lead == 0) { d.zIlo = d.zIhi = e->dc_z[0]; d.zQlo = d.zQhi = e->dc_z[1]; }       // the stream's own state
-    else { d.zIlo = lo_of (j, 0); d.zIhi = hi_of (j, 0); d.zQlo = lo_of (j, 1); d.zQhi = hi_of (j, 1); }
+    else if (c == 0) { d.zIlo = lo_of (j, 0); d.zIhi = hi_of (j, 0); d.zQlo = lo_of (j, 1); d.zQhi = hi_of (j, 1); }
+    else { d.zIlo = d.zIhi = mid_of (j, 0); d.zQlo = d.zQhi = mid_of (j, 1); }
   }
   // slots 0 .. K-1: the chunks; K .. 2K-1: repairs of a chunk's first samples; 2K: a chunk re-run as a whole
+  const uint32_t nck = uint32_t (L / kDcCkpt + 1);
   if ((rc = e->dc_desc.reserve (2 * K + 1)) != MODES_OK) return rc;
   if ((rc = e->dc_zs.reserve (4 * (2 * K + 1))) != MODES_OK) return rc;
   if ((rc = e->dc_ze.reserve (2 * (2 * K + 1))) != MODES_OK) return rc;
   if ((rc = e->dc_zc.reserve (2 * (2 * K + 1))) != MODES_OK) return rc;
   if ((rc = e->dc_closed.reserve (2 * K + 1)) != MODES_OK) return rc;
   if ((rc = e->dc_unm.reserve (2 * K + 1 + 16)) != MODES_OK) return rc;
+  if ((rc = e->dc_ckpt.reserve (2 * size_t (K) * nck)) != MODES_OK) return rc;
   DcParams q;
   memset (&q, 0, sizeof q);
   q.iq = static_cast<const uint8_t *> (d_iq) - back * bps;
@@ -492,6 +502,7 @@ int prepare_dc (modes_engine *e, const void *d_iq, size_t nbytes, const uint16_t
     q.mag_sq = e->dc_sq.p;
   }
   q.z_start = e->dc_zs.p; q.z_end = e->dc_ze.p; q.unmerged = e->dc_unm.p; q.closed_at = e->dc_closed.p; q.z_close = e->dc_zc.p;
+  q.ckpt = e->dc_ckpt.p; q.nck = nck;
   q.rounds = reinterpret_cast<unsigned long long *> (e->dc_unm.p + ((2 * K + 2) & ~1ull));
   HIP_TRY (hipMemsetAsync (q.rounds, 0, 6 * sizeof (unsigned long long), stream));
   const bool profile = getenv ("MODES_DC_PROFILE") != nullptr;
@@ -507,12 +518,9 @@ int prepare_dc (modes_engine *e, const void *d_iq, size_t nbytes, const uint16_t
   HIP_TRY (hipEventRecord (e->dc_ev[1], stream));
   // read-backs land in vectors that outlive every wait below: an early return synchronises first (SyncOnExit)
   struct SyncOnExit { hipStream_t s; ~SyncOnExit () { (void) hipStreamSynchronize (s); } } sync_guard { stream };
-  std::vector<float> zs (4 * K), ze (2 * K), zc (2 * K);
+  std::vector<float> zs (4 * K), ze (2 * K);
   std::vector<uint32_t> unm (K);
-  std::vector<long long> closed (K);
   unsigned long long rounds[6] = { 0, 0, 0, 0, 0, 0 };
-  HIP_TRY (hipMemcpyAsync (zc.data (), e->dc_zc.p, 2 * K * sizeof (float), hipMemcpyDeviceToHost, stream));
-  HIP_TRY (hipMemcpyAsync (closed.data (), e->dc_closed.p, K * sizeof (long long), hipMemcpyDeviceToHost, stream));
   HIP_TRY (hipMemcpyAsync (zs.data (), e->dc_zs.p, 4 * K * sizeof (float), hipMemcpyDeviceToHost, stream));
   HIP_TRY (hipMemcpyAsync (ze.data (), e->dc_ze.p, 2 * K * sizeof (float), hipMemcpyDeviceToHost, stream));
   HIP_TRY (hipMemcpyAsync (unm.data (), e->dc_unm.p, K * sizeof (uint32_t), hipMemcpyDeviceToHost, stream));
@@ -529,71 +537,76 @@ int prepare_dc (modes_engine *e, const void *d_iq, size_t nbytes, const uint16_t
     std::sort (order.begin (), order.end (), [&] (uint64_t a, uint64_t b) { return tk[16 * a] > tk[16 * b]; });
     for (uint64_t i = 0; i < K && i < 6; i++) {
       const uint64_t c = order[i];
-      fprintf (stderr, "  slowest: chunk %4llu: %9llu ticks, %7llu rounds, %6llu plain, chain %llu, barriers %llu; rounds per wave %llu %llu %llu %llu; start %lld closed_at %lld (chunk begins %llu)\n", (unsigned long long) c, tk[16 * c], tk[16 * c + 1], tk[16 * c + 2], tk[16 * c + 3], tk[16 * c + 4],
-               tk[16 * c + 5], tk[16 * c + 7], tk[16 * c + 9], tk[16 * c + 11], desc[c].start, closed[c], (unsigned long long) (c * L));
+      fprintf (stderr, "  slowest: chunk %4llu: %9llu ticks, %7llu rounds, %6llu plain, chain %llu, barriers %llu; rounds per wave %llu %llu %llu %llu (plain steps, or with DC_COUNT_PASSES passes: I %llu Q %llu); wave 0 at barriers inside the chunk %llu; helper wave 4: work %llu, barriers %llu (inside the chunk %llu); start %lld (chunk begins %llu)\n", (unsigned long long) c, tk[16 * c], tk[16 * c + 1], tk[16 * c + 2], tk[16 * c + 3], tk[16 * c + 4],
+               tk[16 * c + 5], tk[16 * c + 7], tk[16 * c + 9], tk[16 * c + 11], tk[16 * c + 6], tk[16 * c + 10], tk[16 * c + 12], tk[16 * c + 13], tk[16 * c + 14], tk[16 * c + 15], desc[c].start, (unsigned long long) (c * L));
     }
-    uint64_t open_chunks = 0;
-    for (uint64_t c = 0; c < K; c++) open_chunks += unm[c];
-    fprintf (stderr, "dc profile (wave 0 sums over %llu chunks): chain %llu barrier %llu total %llu ticks, longest %llu; warm %llu, %llu chunks with an open bracket\n",
-             (unsigned long long) K, rounds[2], rounds[3], rounds[4], rounds[5], (unsigned long long) warm, (unsigned long long) open_chunks);
+    uint64_t missed = 0;
+    for (uint64_t c = 1; c < K; c++) missed += !(same (zs[4 * c], ze[2 * (c - 1)]) && same (zs[4 * c + 2], ze[2 * (c - 1) + 1]));
+    fprintf (stderr, "dc profile (wave 0 sums over %llu chunks): chain %llu barrier %llu total %llu ticks, longest %llu; warm %llu, %llu chunks entered with another state than the chunk before ended on\n",
+             (unsigned long long) K, rounds[2], rounds[3], rounds[4], rounds[5], (unsigned long long) warm, (unsigned long long) missed);
   }
   for (uint64_t c = 0; c < K; c++) e->dc_info.chain_steps += 2 * uint64_t ((long long) std::min (n_eff, (c + 1) * L) - desc[c].start);
   q.rounds = nullptr;
   q.ticks = nullptr;
   if (unm[0]) return fail (MODES_E_ARG, "filter_dc: a lead-in of %llu samples does not settle the DC filter (about %llu needed)",
                            (unsigned long long) lead, (unsigned long long) warm);
-  // Chunks whose bracket closed only after their first sample: from `closed_at` on their values are final (closed
-  // brackets have met on the true state, if they held it), so only [first sample, closed_at) is stepped again, from
-  // the end state of the chunk before -- all such chunks in one launch.  A repair that does not arrive at the state
-  // the chunk closed on (a bracket that did not hold the true state) sends the chunk to the sequential pass below.
-  std::vector<uint8_t> good (K, 0);              // 1: right as it stands, given that the chunk before ends on ze[c - 1] as read back
-  good[0] = 1;
+  // A chunk entered with another state than the chunk before ended on is stepped again from that end state, all such
+  // chunks in one launch, each only until it has met the trajectory of the first pass (the checkpoints): from there on
+  // the first pass's values stand.  One that never meets it is stepped to its end and hands on a new end state.
   std::vector<DcChunk> fix;
-  std::vector<uint64_t> fix_of;
+  std::vector<long long> fix_idx (K, -1);
   for (uint64_t c = 1; c < K; c++) {
     const float *st = &zs[4 * c], *pe = &ze[2 * (c - 1)];
-    if (!unm[c]) { good[c] = st[0] == pe[0] && st[2] == pe[1]; continue; }
-    if (closed[c] <= (long long) (c * L)) continue;                   // never closed
+    if (same (st[0], pe[0]) && same (st[2], pe[1])) continue;
     DcChunk d;
-    d.start = (long long) (c * L); d.chunk = uint32_t (c); d.slot = uint32_t (K + fix.size ()); d.stop = closed[c];
+    d.start = (long long) (c * L); d.chunk = uint32_t (c); d.slot = uint32_t (K + fix.size ()); d.stop = -1;
     d.zIlo = d.zIhi = pe[0]; d.zQlo = d.zQhi = pe[1];
-    fix.push_back (d); fix_of.push_back (c);
+    fix_idx[c] = (long long) fix.size ();
+    fix.push_back (d);
   }
+  std::vector<float> fe (2 * fix.size () + 2);
+  std::vector<long long> fclosed (fix.size () + 1);
   if (!fix.empty ()) {
-    std::vector<float> fe (2 * fix.size ());
     HIP_TRY (hipMemcpyAsync (e->dc_desc.p + K, fix.data (), fix.size () * sizeof (DcChunk), hipMemcpyHostToDevice, stream));
     q.desc = e->dc_desc.p + K;
     HIP_TRY (hipEventRecord (e->dc_ev[2], stream));
     HIP_TRY (launch_dc_chain (e->conv, q, uint32_t (fix.size ()), stream));
     HIP_TRY (hipEventRecord (e->dc_ev[3], stream));
-    HIP_TRY (hipMemcpyAsync (fe.data (), e->dc_ze.p + 2 * K, fe.size () * sizeof (float), hipMemcpyDeviceToHost, stream));
+    HIP_TRY (hipMemcpyAsync (fe.data (), e->dc_ze.p + 2 * K, 2 * fix.size () * sizeof (float), hipMemcpyDeviceToHost, stream));
+    HIP_TRY (hipMemcpyAsync (fclosed.data (), e->dc_closed.p + K, fix.size () * sizeof (long long), hipMemcpyDeviceToHost, stream));
     HIP_TRY (hipStreamSynchronize (stream));
-    { float ms = 0; (void) hipEventElapsedTime (&ms, e->dc_ev[2], e->dc_ev[3]); e->dc_info.chain_ms += ms; }    // chain_ms: every launch of the chain kernel
-    for (size_t i = 0; i < fix.size (); i++) {
-      const uint64_t c = fix_of[i];
-      good[c] = fe[2 * i] == zc[2 * c] && fe[2 * i + 1] == zc[2 * c + 1];
-    }
+    { float ms = 0; (void) hipEventElapsedTime (&ms, e->dc_ev[2], e->dc_ev[3]); e->dc_info.chain_ms += ms;      // chain_ms: every launch of the chain kernel
+      if (profile) {
+        long long far = 0;
+        for (size_t i = 0; i < fix.size (); i++) far = std::max (far, (fclosed[i] < 0 ? (long long) L : fclosed[i] - fix[i].start));
+        fprintf (stderr, "dc profile: first pass %.3f ms; %zu chunks stepped again in %.3f ms, the longest for %lld samples\n", e->dc_info.chain_ms - ms, fix.size (), ms, far);
+      } }
     e->dc_info.prefix_reruns = uint32_t (fix.size ());
   }
-  // in order: whatever is not proven is stepped again as a whole from the exact state; a chunk behind one whose end
-  // state changed is only good if it was built on the new value
-  std::vector<float> assumed (ze);               // the end states the `good` flags were formed against
+  // In order: what a chunk really ends on.  Whatever was checked or repaired against an end state that has changed since
+  // is stepped again as a whole from the right one.
+  std::vector<float> true_end (ze);
   for (uint64_t c = 1; c < K; c++) {
-    const float *pe = &ze[2 * (c - 1)];
-    if (good[c] && assumed[2 * (c - 1)] == pe[0] && assumed[2 * (c - 1) + 1] == pe[1]) continue;
+    const float *te = &true_end[2 * (c - 1)];
+    if (same (te[0], ze[2 * (c - 1)]) && same (te[1], ze[2 * (c - 1) + 1])) {      // built on what the chunk before does end on
+      const long long i = fix_idx[c];
+      if (i >= 0 && fclosed[i] < 0) { true_end[2 * c] = fe[2 * i]; true_end[2 * c + 1] = fe[2 * i + 1]; }   // never met the first pass
+      continue;
+    }
     DcChunk d;
     d.start = (long long) (c * L); d.chunk = uint32_t (c); d.slot = uint32_t (2 * K); d.stop = 0;
-    d.zIlo = d.zIhi = pe[0]; d.zQlo = d.zQhi = pe[1];
+    d.zIlo = d.zIhi = te[0]; d.zQlo = d.zQhi = te[1];
     HIP_TRY (hipMemcpyAsync (e->dc_desc.p + 2 * K, &d, sizeof d, hipMemcpyHostToDevice, stream));
     q.desc = e->dc_desc.p + 2 * K;
     HIP_TRY (hipEventRecord (e->dc_ev[2], stream));
     HIP_TRY (launch_dc_chain (e->conv, q, 1, stream));
     HIP_TRY (hipEventRecord (e->dc_ev[3], stream));
-    HIP_TRY (hipMemcpyAsync (&ze[2 * c], e->dc_ze.p + 2 * (2 * K), 2 * sizeof (float), hipMemcpyDeviceToHost, stream));
+    HIP_TRY (hipMemcpyAsync (&true_end[2 * c], e->dc_ze.p + 2 * (2 * K), 2 * sizeof (float), hipMemcpyDeviceToHost, stream));
     HIP_TRY (hipStreamSynchronize (stream));
     { float ms = 0; (void) hipEventElapsedTime (&ms, e->dc_ev[2], e->dc_ev[3]); e->dc_info.chain_ms += ms; }
     e->dc_info.rerun_chunks++;
   }
+  ze = true_end;
   e->dc_z[0] = ze[2 * (K - 1)]; e->dc_z[1] = ze[2 * (K - 1) + 1];
   if (q.mag_sq) {
     // mag_buf.mean_power of every block: the converter's float running sum over the block's squared magnitudes, in
@@ -1081,7 +1094,7 @@ void modes_engine_destroy (modes_engine *e)
   e->block_power.release (); e->noise_level.release ();
   e->raw_len.release (); e->raw_off.release (); e->raw_cs.release (); e->raw_cv.release (); e->raw_co.release (); e->raw_text.release ();
   if (e->pin_text) (void) hipHostFree (e->pin_text);
-  e->dc_lin.release (); e->dc_ticks.release (); e->dc_zc.release (); e->dc_closed.release ();
+  e->dc_lin.release (); e->dc_ticks.release (); e->dc_zc.release (); e->dc_ckpt.release (); e->dc_closed.release ();
   for (hipEvent_t ev : e->dc_ev) if (ev) (void) hipEventDestroy (ev);
   if (e->dc_power_done) (void) hipEventDestroy (e->dc_power_done);
   for (hipEvent_t ev : e->round_ev) if (ev) (void) hipEventDestroy (ev);

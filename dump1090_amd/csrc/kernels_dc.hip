@@ -107,45 +107,30 @@ __device__ __forceinline__ float bcast_lane (float x, int l)
 // mean of RN (t) falls between two integers, and z1 dithers across the point where k changes.
 // A pass is accepted up to the first lane whose start differs, bit for bit, from the value the lane below ended on:
 // exact by induction from z0, whatever the guesses were.
-// tk[q] = t of sample kDcPer * lane + q; nl = lanes that hold samples.  On return zt[q] = z1 behind that sample as
-// stepped from the lane's start; the result is the number of leading lanes whose values are proven (>= 1).
-__device__ __forceinline__ int dc_round (const float *tk, float z0, float B, int lane, int nl, float *zt, float &leak_adj, uint32_t &n_pass)
+// tk[q] = t of sample kDcPer * lane + q; nl = lanes that hold samples (lanes beyond hold anything), nlmask = their mask.
+// On return zt[q] = z1 behind that sample as stepped from the lane's start; the result is the number of leading lanes
+// whose values are proven (>= 1).
+// The round is a string of dependent operations and is paid for in latency, so: the sum of the first guess is a tree,
+// the lane below is fetched with the proven z0 as lane 0's old value (no select), the verdict is one compare.
+__device__ __forceinline__ int dc_round (const float *tk, float z0, float B, int lane, int nl, u64 nlmask, float *zt, uint32_t &n_pass)
 {
   // first guess: the filter in real arithmetic, z' = z + t - z (1 - B), with z ~ z0 over the round
-  float start, guess_end;
+  float start;
   {
-    float ts = 0.0f;
+    float part[kDcPer];
 #pragma unroll
-    for (int q = 0; q < kDcPer; q++) ts += tk[q];
-    // What z1 loses per step: z - RN (z * B) at z0, an integer number of ulps -- where the filter has settled (an input
-    // with a DC component and little else) z1 dithers across the point where that integer changes, and the loss per
-    // step is in between: `leak_adj` carries the average the last complete round really lost beyond it.
-#ifndef DC_LEAK_ADJ
-    leak_adj = 0.0f;                      // (measured: the passes a round needs do not hang on the first guess; 4 % slower with it)
-#endif
-    const float leak = (z0 - z0 * B) + leak_adj;
-    const float inc = ts - float (kDcPer) * leak;
+    for (int q = 0; q < kDcPer; q++) part[q] = tk[q];
+#pragma unroll
+    for (int w = kDcPer / 2; w >= 1; w >>= 1)
+#pragma unroll
+      for (int q = 0; q < w; q++) part[q] += part[q + w];
+    // what z1 loses per step: z - RN (z * B) at z0, an integer number of ulps
+    const float leak = z0 - z0 * B;
+    const float inc = part[0] - float (kDcPer) * leak;
     const float incl = wave_incl_scan_f (inc);
     start = z0 + (incl - inc);
-    guess_end = bcast_lane (z0 + incl, nl - 1);
   }
   int good = 1;
-#ifdef DC_RESTART
-#pragma unroll 1
-  for (int it = 0; it < kDcIters; it++) {
-    float z = start;
-#pragma unroll
-    for (int q = 0; q < kDcPer; q++) { z = __fadd_rn (tk[q], __fmul_rn (z, B)); zt[q] = z; }
-    float below = __uint_as_float (dpp_mov<0x138, 0xF, true> (__float_as_uint (z)));     // wave_shr:1: the lane below
-    if (lane == 0) below = z0;
-    const u64 bad = __ballot (__float_as_uint (below) != __float_as_uint (start) && lane < nl);
-    good = bad ? __builtin_ctzll (bad) : nl;
-    if (good == nl || it == kDcIters - 1) break;
-    const float inc = __fsub_rn (z, start);
-    const float incl = wave_incl_scan_f (inc);
-    start = __fadd_rn (z0, __fsub_rn (incl, inc));
-  }
-#else
   // Lanes below `good` are proven and keep their starts; the others take theirs from the end of the last proven lane
   // plus the increments the lanes between them made in this pass -- sums that start at the proven front, so they stay
   // small and exact where the chain sits still, and the pass after a miss starts from this pass's knowledge instead of
@@ -158,9 +143,9 @@ __device__ __forceinline__ int dc_round (const float *tk, float z0, float B, int
 #endif
 #pragma unroll
     for (int q = 0; q < kDcPer; q++) { z = __fadd_rn (tk[q], __fmul_rn (z, B)); zt[q] = z; }
-    float below = __uint_as_float (dpp_mov<0x138, 0xF, true> (__float_as_uint (z)));     // wave_shr:1: the lane below
-    if (lane == 0) below = z0;
-    const u64 bad = __ballot (__float_as_uint (below) != __float_as_uint (start) && lane < nl);
+    // wave_shr:1 = the lane below; lane 0 has none and keeps the `old` operand: z0 itself
+    const uint32_t below = uint32_t (__builtin_amdgcn_update_dpp (int (__float_as_uint (z0)), int (__float_as_uint (z)), 0x138, 0xF, 0xF, false));
+    const u64 bad = __ballot (below != __float_as_uint (start)) & nlmask;
     good = bad ? __builtin_ctzll (bad) : nl;      // (a proven lane's start never changes below, so it is never the first miss)
     if (good == nl || it == kDcIters - 1) break;
     const float zg = bcast_lane (z, good - 1);    // the proven front: z1 in front of lane `good`
@@ -168,20 +153,28 @@ __device__ __forceinline__ int dc_round (const float *tk, float z0, float B, int
     const float incl = wave_incl_scan_f (inc);
     if (lane >= good) start = __fadd_rn (zg, __fsub_rn (incl, inc));
   }
-#endif
-  if (good == nl) {      // what the first guess missed, per step, goes into the next round's guess
-    const float true_end = bcast_lane (zt[kDcPer - 1], nl - 1);
-    leak_adj += (guess_end - true_end) / float (kDcPer * nl);
-  }
   return good;
 }
 
 // One chain over t[0 .. cnt): returns z1 behind the last sample, zo[i] = z1 behind sample i.  z0 is uniform.
 // t and zo are 16-byte aligned and hold kDcBatch entries (entries at and beyond cnt are never used in a result).
-__device__ __forceinline__ float dc_chain_batch (const float *t, float *zo, bool store, int cnt, float z0, float B, int lane, uint32_t &n_guess, uint32_t &n_plain, float &leak_adj)
+// Two register sets alternate: while one round is stepped the t values of the round behind it are on their way from LDS
+// (on the bet that the round is accepted whole, as nearly all are; after a partial round the set is fetched again).
+__device__ __forceinline__ float dc_chain_batch (const float *t, float *zo, bool store, int cnt, float z0, float B, int lane, uint32_t &n_guess, uint32_t &n_plain)
 {
   int base = 0;
-  while (base < cnt) {
+  // (lanes beyond the round's last sample fetch whatever the buffer's last entries hold: nothing of theirs reaches a
+  // result -- the prefix sums run upwards, the verdict is masked, the broadcasts read proven lanes)
+  auto load = [&] (float *tk, int at) {
+    const float4 *src = reinterpret_cast<const float4 *> (t + dcp (min (at + kDcPer * lane, kDcBatch - kDcPer)));
+#pragma unroll
+    for (int g = 0; g < kDcPer / 4; g++) { const float4 x = src[g]; tk[4 * g] = x.x; tk[4 * g + 1] = x.y; tk[4 * g + 2] = x.z; tk[4 * g + 3] = x.w; }
+  };
+  auto lanes_at = [&] (int at) { const int rem = cnt - at; return rem >= kDcRound ? 64 : rem / kDcPer; };
+  // one round on `cur` (fetched here unless the round before has done so), the next one's values into `nxt` meanwhile;
+  // false: the batch is through
+  auto step = [&] (float *cur, float *nxt, bool &have) -> bool {
+    if (base >= cnt) return false;
     const int rem = cnt - base;
     if (rem < kDcPer) {                            // ragged end of the stream: plain steps (ref: src/convert.c:137-140)
       float z = z0;
@@ -189,20 +182,16 @@ __device__ __forceinline__ float dc_chain_batch (const float *t, float *zo, bool
       for (int i = 0; i < rem; i++) { z = __fadd_rn (t[dcp (base + i)], __fmul_rn (z, B)); if (st) zo[dcp (base + i)] = z; }
       z0 = z;
       base += rem; n_plain++;
-      continue;
+      return false;
     }
     n_guess++;
-    const int nl = rem >= kDcRound ? 64 : rem / kDcPer;          // lanes that hold samples of this batch
-    float tk[kDcPer], zt[kDcPer];
-    if (lane < nl) {
-      const float4 *src = reinterpret_cast<const float4 *> (t + dcp (base + kDcPer * lane));
-#pragma unroll
-      for (int g = 0; g < kDcPer / 4; g++) { const float4 x = src[g]; tk[4 * g] = x.x; tk[4 * g + 1] = x.y; tk[4 * g + 2] = x.z; tk[4 * g + 3] = x.w; }
-    } else {
-#pragma unroll
-      for (int q = 0; q < kDcPer; q++) tk[q] = 0.0f;
-    }
-    const int good = dc_round (tk, z0, B, lane, nl, zt, leak_adj, n_plain);         // >= 1: lane 0 starts from z0 itself
+    const int nl = lanes_at (base);                // lanes that hold samples of this round
+    if (!have) load (cur, base);
+    const int nb = base + kDcPer * nl;
+    const bool ahead = cnt - nb >= kDcPer;
+    if (ahead) load (nxt, nb);
+    float zt[kDcPer];
+    const int good = dc_round (cur, z0, B, lane, nl, nl == 64 ? ~0ull : (1ull << nl) - 1, zt, n_plain);      // >= 1: lane 0 starts from z0 itself
     if (store && lane < good) {
       float4 *dst = reinterpret_cast<float4 *> (zo + dcp (base + kDcPer * lane));
 #pragma unroll
@@ -210,150 +199,196 @@ __device__ __forceinline__ float dc_chain_batch (const float *t, float *zo, bool
     }
     z0 = bcast_lane (zt[kDcPer - 1], good - 1);
     base += kDcPer * good;
+    have = ahead && good == nl;
+    return true;
+  };
+  float tkA[kDcPer], tkB[kDcPer];
+  bool have = false;
+  for (;;) {
+    if (!step (tkA, tkB, have)) break;
+    if (!step (tkB, tkA, have)) break;
   }
   return z0;
 }
 
-// Magnitudes of samples [b + off, b + off + 2048) of a batch whose z1 values lie in zI / zQ (ref: src/convert.c:139-147):
-// one wave, 32 samples per lane in eight goes of four.  The raw samples are read again (they were staged a batch ago:
-// L2 holds them), all eight loads in flight before the first conversion.
+// Magnitudes of four consecutive samples per lane -- samples [b + o, b + o + 4) of a batch whose z1 values lie in zI / zQ
+// (ref: src/convert.c:139-147); `raw` holds their IQ.
 template <int CONV>
-__device__ __forceinline__ void dc_magnitudes_half (const DcParams &p, const float *uc8f, const float *zI, const float *zQ,
-                                                    long long b, int off, int cnt, long long c1, int lane)
+__device__ __forceinline__ void dc_magnitudes_go (const DcParams &p, const float *uc8f, const float *zI, const float *zQ,
+                                                  const DcRaw<CONV> &raw, long long b, int o, int cnt)
 {
-  constexpr int kGo = kDcBatch / 2 / 256;
-  DcRaw<CONV> raw[kGo];
+  if (o >= cnt) return;
+  float fI[4], fQ[4];
+  dc_to_float<CONV> (raw, uc8f, fI, fQ);
+  const float4 a = *reinterpret_cast<const float4 *> (zI + o);
+  const float4 c = *reinterpret_cast<const float4 *> (zQ + o);
+  const float zi[4] = { a.x, a.y, a.z, a.w }, zq[4] = { c.x, c.y, c.z, c.w };
+  uint32_t m[4];
+  float sq[4];
 #pragma unroll
-  for (int g = 0; g < kGo; g++) dc_load4<CONV> (p.iq, b + off + 256 * g + 4 * lane, c1, raw[g]);
+  for (int k = 0; k < 4; k++)
+    m[k] = mag_from_float (__fsub_rn (fI[k], zi[k]), __fsub_rn (fQ[k], zq[k]), &sq[k]);
+  if (p.mag_sq) {                      // b and o are multiples of 4: whole float4s (the slack behind [n] takes the ragged end)
+    float4 q4; q4.x = sq[0]; q4.y = sq[1]; q4.z = sq[2]; q4.w = sq[3];
+    *reinterpret_cast<float4 *> (p.mag_sq + b + o) = q4;
+  }
+  uint16_t *dst = p.mag + b + o;
+  if (o + 4 <= cnt) {
+    uint32_t *d32 = reinterpret_cast<uint32_t *> (dst);          // p.mag is 4-byte aligned, b and o are even
+    d32[0] = m[0] | (m[1] << 16); d32[1] = m[2] | (m[3] << 16);
+  } else {
 #pragma unroll
-  for (int g = 0; g < kGo; g++) {
-    const int o = off + 256 * g + 4 * lane;
-    if (o >= cnt) break;
-    float fI[4], fQ[4];
-    dc_to_float<CONV> (raw[g], uc8f, fI, fQ);
-    const float4 a = *reinterpret_cast<const float4 *> (zI + o);
-    const float4 c = *reinterpret_cast<const float4 *> (zQ + o);
-    const float zi[4] = { a.x, a.y, a.z, a.w }, zq[4] = { c.x, c.y, c.z, c.w };
-    uint32_t m[4];
-    float sq[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      m[k] = mag_from_float (__fsub_rn (fI[k], zi[k]), __fsub_rn (fQ[k], zq[k]), &sq[k]);
-    if (p.mag_sq) {                      // b and o are multiples of 4: whole float4s (the slack behind [n] takes the ragged end)
-      float4 q4; q4.x = sq[0]; q4.y = sq[1]; q4.z = sq[2]; q4.w = sq[3];
-      *reinterpret_cast<float4 *> (p.mag_sq + b + o) = q4;
-    }
-    uint16_t *dst = p.mag + b + o;
-    if (o + 4 <= cnt) {
-      uint32_t *d32 = reinterpret_cast<uint32_t *> (dst);          // p.mag is 4-byte aligned, b and o are even
-      d32[0] = m[0] | (m[1] << 16); d32[1] = m[2] | (m[3] << 16);
-    } else {
-#pragma unroll
-      for (int k = 0; k < 4; k++) if (o + k < cnt) dst[k] = uint16_t (m[k]);
-    }
+    for (int k = 0; k < 4; k++) if (o + k < cnt) dst[k] = uint16_t (m[k]);
   }
 }
 
-// One workgroup per chunk.  Waves 0 / 2 run the chains I-lo / Q-lo, waves 1 / 3 the chains I-hi / Q-hi until their
-// bracket has closed -- which it has, for all but a few chunks, before the chunk's own samples begin.  From then on the
-// two hi waves have nothing to step, and form the magnitudes of the batch BEFORE the one the lo waves are stepping: the
-// lo chains write z1 over the t values they have consumed (same LDS slot, same lane), two batch buffers alternate, and
-// the magnitude work (as long as a batch's chain rounds) leaves the critical path.  A batch of the chunk's own samples
-// stepped while a bracket was still open gets no magnitudes here: the host steps [first sample, closed_at) again from
-// the exact state (prepare_dc), brackets closed from the start.
+// One workgroup of eight waves per chunk.  A chain is a string of dependent operations: what a chunk costs is the
+// number of its rounds times the latency of one, and nothing else may stand in the way of the wave that steps it.
+//   waves 0 / 2   the chains of I and Q (the `lo` values of the descriptor) -- they do nothing but step, batch after
+//                 batch, and leave z1 over the t values they have consumed (same LDS slot, same lane);
+//   waves 1 / 3   the same samples from the `hi` values where the descriptor holds a bracket (a shard's first chunk behind
+//                 a lead-in: nothing earlier can vouch for its state); helpers otherwise;
+//   helpers       (waves 4 .. 7, and 1 / 3 when there is no bracket) take every fourth / sixth go of 256 samples of every
+//                 batch: the magnitudes of the batch BEFORE the one being stepped (from the z1 the chains left), then
+//                 t = f * DC_A of the batch AFTER it into the very slots just read; the raw samples of the batch behind
+//                 that are in flight meanwhile.
+// Two batch buffers alternate; one barrier a batch.
+// Exactness does not rest on a bracket: the host accepts a chunk when the state it was in at its first sample IS, bit for
+// bit, the state the chunk before ended on (induction from the stream's first sample).  To repair a chunk that was not,
+// the kernel writes the chains' state every kDcCkpt samples (`ckpt`); a descriptor with stop == -1 steps the chunk again
+// from the exact state and stops at the first checkpoint where it has met the trajectory of the first pass -- from there
+// on both are the same chain.
 template <int CONV>
-__global__ __launch_bounds__ (256)
+__global__ __launch_bounds__ (512) __attribute__ ((amdgpu_waves_per_eu (4, 4)))
 void dc_chain_kernel (const DcParams p)
 {
   __shared__ __attribute__ ((aligned (16))) float s_buf[2][2][kDcBatchLds];   // [batch parity][channel]: f * DC_A, then z1 in place
   __shared__ float s_uc8[256];
-  __shared__ float s_state[4];                                        // I-lo, I-hi, Q-lo, Q-hi behind the last batch
+  __shared__ float s_state[2][4];                                     // [batch parity] I-lo, I-hi, Q-lo, Q-hi in front of the batch
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane (tid >> 6);
   const DcChunk d = p.desc[blockIdx.x];
-  if (CONV == kConvUc8Generic) s_uc8[tid] = float ((double (tid) - 127.5) / 127.5);       // ref: src/convert.c:131
-  if (tid == 0) { s_state[0] = d.zIlo; s_state[1] = d.zIhi; s_state[2] = d.zQlo; s_state[3] = d.zQhi; }
+  const bool bracket = __float_as_uint (d.zIlo) != __float_as_uint (d.zIhi) || __float_as_uint (d.zQlo) != __float_as_uint (d.zQhi);
+  const bool helper = wv >= 4 || (!bracket && (wv & 1));
+  const int nh = bracket ? 4 : 6;                                     // helpers
+  const int hidx = wv >= 4 ? wv - 4 : 4 + (wv >> 1);                  // this helper takes goes hidx, hidx + nh, ... of every batch
+  constexpr int kGoes = kDcBatch / 256, NG = (kGoes + 3) / 4;         // goes of 256 samples (four per lane) in a batch; most goes a helper takes
+  if (CONV == kConvUc8Generic && tid < 256) s_uc8[tid] = float ((double (tid) - 127.5) / 127.5);       // ref: src/convert.c:131
+  if (tid == 0) { s_state[0][0] = d.zIlo; s_state[0][1] = d.zIhi; s_state[0][2] = d.zQlo; s_state[0][3] = d.zQhi; }
   __syncthreads ();
   const long long c0 = (long long) d.chunk * (long long) p.chunk_len;
   const long long c1 = d.stop > 0 ? d.stop : min (c0 + (long long) p.chunk_len, (long long) p.n);
+  const bool cmp = d.stop == -1;
   bool noted = false;
   float z = wv == 0 ? d.zIlo : wv == 1 ? d.zIhi : wv == 2 ? d.zQlo : d.zQhi;
   const float A = p.A, B = p.B;
   uint32_t n_guess = 0, n_plain = 0;
-  float leak_adj = 0.0f;
-  long long tm_chain = 0, tm_bar = 0, tm_total = clock64 ();
+  long long tm_chain = 0, tm_bar = 0, tm_bar_region = 0, tm_total = clock64 ();
 
-  constexpr int NG = kDcBatch / 1024;                                // groups of 1024 samples: four per thread each
-  DcRaw<CONV> raw[NG];
+  DcRaw<CONV> raw[NG];                                                // IQ of the batch to stage next
+  auto fetch = [&] (long long b, DcRaw<CONV> *r) {
 #pragma unroll
-  for (int g = 0; g < NG; g++) dc_load4<CONV> (p.iq, d.start + 1024 * g + 4 * tid, c1, raw[g]);
+    for (int k = 0; k < NG; k++) { const int go = hidx + nh * k; if (go < kGoes) dc_load4<CONV> (p.iq, b + 256 * go + 4 * lane, c1, r[k]); }
+  };
+  auto stage = [&] (int par) {
+#pragma unroll
+    for (int k = 0; k < NG; k++) {
+      const int go = hidx + nh * k;
+      if (go >= kGoes) break;
+      float fI[4], fQ[4];
+      dc_to_float<CONV> (raw[k], s_uc8, fI, fQ);
+      float4 tI, tQ;
+      tI.x = __fmul_rn (fI[0], A); tI.y = __fmul_rn (fI[1], A); tI.z = __fmul_rn (fI[2], A); tI.w = __fmul_rn (fI[3], A);
+      tQ.x = __fmul_rn (fQ[0], A); tQ.y = __fmul_rn (fQ[1], A); tQ.z = __fmul_rn (fQ[2], A); tQ.w = __fmul_rn (fQ[3], A);
+      *reinterpret_cast<float4 *> (&s_buf[par][0][dcp (256 * go + 4 * lane)]) = tI;
+      *reinterpret_cast<float4 *> (&s_buf[par][1][dcp (256 * go + 4 * lane)]) = tQ;
+    }
+  };
+  auto magnitudes = [&] (int par, long long b, int cnt) {             // of batch b, whose z1 lie in s_buf[par]; its IQ is read again (L2 holds it)
+    DcRaw<CONV> rawm[NG];
+    fetch (b, rawm);
+#pragma unroll
+    for (int k = 0; k < NG; k++) {
+      const int go = hidx + nh * k;
+      if (go >= kGoes) break;
+      dc_magnitudes_go<CONV> (p, s_uc8, s_buf[par][0], s_buf[par][1], rawm[k], b, 256 * go + 4 * lane, cnt);
+    }
+  };
+  if (helper && d.start < c1) {
+    fetch (d.start, raw);
+    stage (0);
+    if (d.start + kDcBatch < c1) fetch (d.start + kDcBatch, raw);
+  }
+  __syncthreads ();
   int pb = 0;                                                        // parity of the batch being stepped
+  int ck_wait = 0, ck_idx = 0;                                       // batches until the next checkpoint (the first is the chunk's first sample), its index
   bool prev_ok = false;                                              // the batch before holds z1 of both channels and wants magnitudes
   long long prev_b = 0;
   int prev_cnt = 0;
   for (long long b = d.start; b < c1; b += kDcBatch, pb ^= 1) {
-#pragma unroll
-    for (int g = 0; g < NG; g++) {
-      float fI[4], fQ[4];
-      dc_to_float<CONV> (raw[g], s_uc8, fI, fQ);
-      if (b + kDcBatch < c1) dc_load4<CONV> (p.iq, b + kDcBatch + 1024 * g + 4 * tid, c1, raw[g]);   // next batch, in flight behind the chains
-      float4 tI, tQ;
-      tI.x = __fmul_rn (fI[0], A); tI.y = __fmul_rn (fI[1], A); tI.z = __fmul_rn (fI[2], A); tI.w = __fmul_rn (fI[3], A);
-      tQ.x = __fmul_rn (fQ[0], A); tQ.y = __fmul_rn (fQ[1], A); tQ.z = __fmul_rn (fQ[2], A); tQ.w = __fmul_rn (fQ[3], A);
-      *reinterpret_cast<float4 *> (&s_buf[pb][0][dcp (1024 * g + 4 * tid)]) = tI;
-      *reinterpret_cast<float4 *> (&s_buf[pb][1][dcp (1024 * g + 4 * tid)]) = tQ;
-    }
     // the states the chains hold in front of this batch
-    const float sIlo = s_state[0], sIhi = s_state[1], sQlo = s_state[2], sQhi = s_state[3];
-    long long tb = clock64 ();
-    __syncthreads ();
-    tm_bar += clock64 () - tb;
+    const float sIlo = s_state[pb][0], sIhi = s_state[pb][1], sQlo = s_state[pb][2], sQhi = s_state[pb][3];
     const bool region = b >= c0;
     const bool both_closed = sIlo == sIhi && sQlo == sQhi;
-    if (b == c0 && tid == 0) {            // first sample of the chunk: have the brackets closed?
+    if (b == c0 && tid == 0) {            // first sample of the chunk: the state it is entered with (have the brackets closed?)
       float *zs = p.z_start + 4 * size_t (d.slot);
       zs[0] = sIlo; zs[1] = sIhi; zs[2] = sQlo; zs[3] = sQhi;
       p.unmerged[d.slot] = both_closed ? 0u : 1u;
     }
-    if (region && !noted && both_closed) {                          // from here on the chunk's values are final
+    if (region && ck_wait-- == 0) {
+      ck_wait = kDcCkpt / kDcBatch - 1;
+      float *ck = p.ckpt + 2 * (size_t (d.chunk) * p.nck + size_t (ck_idx++));
+      if (cmp) {                          // has this chain met the first pass's?  (uniform: every thread reads the same two values)
+        const uint32_t eI = __builtin_amdgcn_readfirstlane (__float_as_uint (ck[0])), eQ = __builtin_amdgcn_readfirstlane (__float_as_uint (ck[1]));
+        if (eI == __float_as_uint (sIlo) && eQ == __float_as_uint (sQlo)) {
+          noted = true;
+          if (tid == 0) { p.closed_at[d.slot] = b; p.z_close[2 * size_t (d.slot)] = sIlo; p.z_close[2 * size_t (d.slot) + 1] = sQlo; }
+          break;
+        }
+      } else if (tid == 0) { ck[0] = sIlo; ck[1] = sQlo; }
+    }
+    if (!cmp && region && !noted && both_closed) {                  // from here on the chunk's values are those of ONE chain
       noted = true;
       if (tid == 0) { p.closed_at[d.slot] = b; p.z_close[2 * size_t (d.slot)] = sIlo; p.z_close[2 * size_t (d.slot) + 1] = sQlo; }
     }
     const int cnt = int (min ((long long) kDcBatch, c1 - b));
-    const bool closed = (wv & 1) && (wv == 1 ? sIlo == sIhi : sQlo == sQhi);     // a hi chain that has met its lo chain
     const bool keep_z = region && both_closed;                      // the lo chains leave z1 in the batch buffer
-    if (!closed) {
+    if (!helper) {
+      const bool closed = (wv & 1) && (wv == 1 ? sIlo == sIhi : sQlo == sQhi);     // a hi chain that has met its lo chain
+      if (!closed) {
+        const long long tc = clock64 ();
+        float *t = s_buf[pb][wv >> 1];
+        z = dc_chain_batch (t, t, !(wv & 1) && keep_z, cnt, z, B, lane, n_guess, n_plain);
+        if (lane == 0) {
+          s_state[pb ^ 1][wv] = z;
+          if (!(wv & 1) && (wv == 0 ? sIlo == sIhi : sQlo == sQhi)) s_state[pb ^ 1][wv + 1] = z;   // the closed hi chain follows
+        }
+        tm_chain += clock64 () - tc;
+      }
+    } else {
       const long long tc = clock64 ();
-      float *t = s_buf[pb][wv >> 1];
-      z = dc_chain_batch (t, t, !(wv & 1) && keep_z, cnt, z, B, lane, n_guess, n_plain, leak_adj);
-      if (lane == 0) {
-        s_state[wv] = z;
-        if (!(wv & 1) && (wv == 0 ? sIlo == sIhi : sQlo == sQhi)) s_state[wv + 1] = z;   // the closed hi chain follows
+      if (prev_ok) magnitudes (pb ^ 1, prev_b, prev_cnt);
+      if (b + kDcBatch < c1) {
+        stage (pb ^ 1);
+        if (b + 2 * kDcBatch < c1) fetch (b + 2 * kDcBatch, raw);
       }
       tm_chain += clock64 () - tc;
-    } else if (prev_ok) {
-      // (prev_ok implies both hi waves are closed: brackets do not open again)
-      dc_magnitudes_half<CONV> (p, s_uc8, s_buf[pb ^ 1][0], s_buf[pb ^ 1][1], prev_b, (wv >> 1) * (kDcBatch / 2), prev_cnt, c1, lane);
     }
-    tb = clock64 ();
+    const long long tb = clock64 ();
     __syncthreads ();
     tm_bar += clock64 () - tb;
-    if (closed) z = s_state[wv];
+    if (region) tm_bar_region += clock64 () - tb;
+    if (!helper && (wv & 1)) z = s_state[pb ^ 1][wv];              // (a closed hi chain follows its lo chain)
     prev_ok = keep_z; prev_b = b; prev_cnt = cnt;
   }
-  if (prev_ok) {                          // the last batch: every wave takes a quarter
-    const int half = (wv >> 1) * (kDcBatch / 2), quarter = (wv & 1) * (kDcBatch / 4);
-    // a half is eight goes of 256 samples; waves 0 / 2 take goes 0..3 of their half, waves 1 / 3 goes 4..7
-    const int cnt_q = min (prev_cnt, half + quarter + kDcBatch / 4);
-    if (half + quarter < prev_cnt)
-      dc_magnitudes_half<CONV> (p, s_uc8, s_buf[pb ^ 1][0], s_buf[pb ^ 1][1], prev_b, half + quarter, cnt_q, c1, lane);
-  }
-  __syncthreads ();
+  if (prev_ok && helper) magnitudes (pb ^ 1, prev_b, prev_cnt);      // the last batch stepped
   if (tid == 0) {
-    p.z_end[2 * size_t (d.slot)] = s_state[0]; p.z_end[2 * size_t (d.slot) + 1] = s_state[2];
+    p.z_end[2 * size_t (d.slot)] = s_state[pb][0]; p.z_end[2 * size_t (d.slot) + 1] = s_state[pb][2];
     if (!noted) p.closed_at[d.slot] = -1;
   }
-  if (lane == 0 && p.ticks) { unsigned long long *o = p.ticks + 16 * size_t (d.chunk) + 5 + 2 * wv; o[0] = n_guess; o[1] = n_plain; }
-  if (lane == 0 && p.rounds) { atomicAdd (&p.rounds[0], (unsigned long long) n_guess); atomicAdd (&p.rounds[1], (unsigned long long) n_plain);
+  if (lane == 0 && wv == 4 && p.ticks) { unsigned long long *o = p.ticks + 16 * size_t (d.chunk) + 13; o[0] = (unsigned long long) tm_chain; o[1] = (unsigned long long) tm_bar; o[2] = (unsigned long long) tm_bar_region; }
+  if (lane == 0 && wv == 0 && p.ticks) p.ticks[16 * size_t (d.chunk) + 12] = (unsigned long long) tm_bar_region;
+  if (lane == 0 && !helper && p.ticks) { unsigned long long *o = p.ticks + 16 * size_t (d.chunk) + 5 + 2 * wv; o[0] = n_guess; o[1] = n_plain; }
+  if (lane == 0 && !helper && p.rounds) { atomicAdd (&p.rounds[0], (unsigned long long) n_guess); atomicAdd (&p.rounds[1], (unsigned long long) n_plain);
     if (wv == 0) { atomicAdd (&p.rounds[2], (unsigned long long) tm_chain); atomicAdd (&p.rounds[3], (unsigned long long) tm_bar); atomicAdd (&p.rounds[4], (unsigned long long) (clock64 () - tm_total)); atomicMax (&p.rounds[5], (unsigned long long) (clock64 () - tm_total)); if (p.ticks) { unsigned long long *o = p.ticks + 16 * size_t (d.chunk); o[0] = (unsigned long long) (clock64 () - tm_total); o[1] = n_guess; o[2] = n_plain; o[3] = (unsigned long long) tm_chain; o[4] = (unsigned long long) tm_bar; } } }
 }
 
@@ -476,7 +511,7 @@ hipError_t launch_dc_linear (int conv, const uint8_t *iq, uint64_t n, double A, 
 hipError_t launch_dc_chain (int conv, const DcParams &p, uint32_t ndesc, hipStream_t stream)
 {
   if (ndesc == 0) return hipSuccess;
-  const dim3 grid (ndesc), block (256);
+  const dim3 grid (ndesc), block (512);
   switch (conv) {
     case kConvUc8Generic:     hipLaunchKernelGGL (dc_chain_kernel<kConvUc8Generic>, grid, block, 0, stream, p); break;
     case kConvSc16Generic:    hipLaunchKernelGGL (dc_chain_kernel<kConvSc16Generic>, grid, block, 0, stream, p); break;
