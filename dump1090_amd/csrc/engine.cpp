@@ -2203,6 +2203,11 @@ int modes_engine_time_scan (modes_engine *e, const void *d_iq, size_t nbytes, in
   int rc = fill_scan_params (e, d_iq, nbytes, nullptr, &sp);
   if (rc != MODES_OK) return rc;
   if (const char *ds = getenv ("MODES_DEBUG_STOP")) sp.debug_stop = atoi (ds);
+  if (e->cfg.filter_dc) {                     // the scan over the magnitudes the last run's DC chain left (same recording)
+    const uint64_t n = nbytes / bytes_per_sample (e->cfg.input_format);
+    if (e->dc_mag.cap < size_t (n) + e->ov + 1024) return fail (MODES_E_ARG, "time_scan with filter_dc: decode the recording first");
+    sp.iq = reinterpret_cast<const uint8_t *> (e->dc_mag.p + 8); sp.conv = kConvMagU16; sp.navail = n + e->ov; sp.halo = nullptr;
+  }
   hipEvent_t a, b;
   HIP_TRY (hipEventCreate (&a));
   HIP_TRY (hipEventCreate (&b));
