@@ -7,14 +7,14 @@
 //
 //   g(z) = RN (t + RN (z * B))   is monotone non-decreasing in z  (RN = round to nearest, B > 0).
 //
-// A chunk of the stream therefore starts its chain `warm` samples early from a bracket lo <= z <= hi around
-// where the filter is in real arithmetic (dc_linear_kernel), steps lo and hi through the very float operations of
-// the reference, and once lo == hi -- and the chunk before ends on the same value -- it IS the reference's z1,
-// whatever the start was (a bracket that missed is caught by the host's check and the chunk re-run).  Chunks are independent; one workgroup of four waves runs one chunk, wave w one of the four chains
-// I-lo, I-hi, Q-lo, Q-hi (the hi waves idle once their bracket has closed); all 256 threads fetch/convert the next
-// 4096 samples and form the magnitudes behind the chains.
-// A chunk whose bracket has not closed at its first sample is reported (`unmerged`, `closed_at`) and repaired by the
-// host from the exact end state of the chunk before it.
+// A chunk of the stream starts its chain `warm` samples early, where the filter is in real arithmetic (dc_linear_kernel),
+// and steps it through the very float operations of the reference.  By the chunk's first sample the start is forgotten --
+// nearly always; the host accepts a chunk only when it enters with the very state the chunk before ended on, so every
+// accepted chunk is the reference's chain by induction from the stream's first sample, and one that is not accepted is
+// stepped again from the right state until it has met the first pass (dc_chain_kernel, prepare_dc in engine.cpp).  A
+// shard's first chunk behind a lead-in has no chunk before it: it steps both ends of a bracket lo <= z <= hi, which the
+// monotone g keeps in order, and is right once lo == hi.  Chunks are independent; one workgroup of eight waves runs one:
+// two chain waves (I, Q), and helpers that stage the next 4096 samples and form the magnitudes behind the chains.
 //
 // A chain is two dependent operations per sample.  A wave therefore steps 1024 samples at once, sixteen per lane,
 // from guessed lane starts that it refines until it can prove them (see dc_round below).

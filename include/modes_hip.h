@@ -341,10 +341,10 @@ int  modes_engine_get_dc_state (const modes_engine *e, float *z1_I, float *z1_Q)
 int  modes_engine_set_dc_lead (modes_engine *e, uint64_t lead_samples, uint64_t warm_samples);
 typedef struct modes_dc_info {
   uint32_t chunks;           /* independent chains of the last run                            */
-  uint32_t rerun_chunks;     /* chunks re-run as a whole from the exact end state of their predecessor */
+  uint32_t rerun_chunks;     /* chunks re-run as a whole, in order, because an earlier chunk's end state changed under them */
   uint64_t chunk_samples, warm_samples;
   float    chain_ms;         /* duration of the chain kernel (HIP events on the launch stream) */
-  uint32_t prefix_reruns;    /* chunks whose first samples (up to where their bracket closed) were stepped again */
+  uint32_t prefix_reruns;    /* chunks that were not entered with their predecessor's end state: their first samples were stepped again, up to where that chain met the first pass's */
   uint64_t guess_rounds;     /* 1024-sample rounds of all chains of the first pass                */
   uint64_t plain_rounds;     /* ragged ends stepped one by one                                     */
   uint64_t chain_steps;      /* filter steps of all chains of the first pass (warm-up included)  */
