@@ -32,11 +32,12 @@ namespace modes {
 // raw IQ of four consecutive samples
 template <int CONV> struct DcRaw { uint32_t w[CONV == kConvUc8Generic ? 2 : 4]; };
 
-template <int CONV>
+// FULL: the caller knows that all four samples lie in front of s_end
+template <int CONV, bool FULL = false>
 __device__ __forceinline__ void dc_load4 (const uint8_t *iq, long long s, long long s_end, DcRaw<CONV> &r)
 {
   constexpr int NW = CONV == kConvUc8Generic ? 2 : 4;
-  if (s + 4 <= s_end) {
+  if (FULL || s + 4 <= s_end) {
     if (CONV == kConvUc8Generic) { const uint2 v = *reinterpret_cast<const uint2 *> (iq + 2 * s); r.w[0] = v.x; r.w[1] = v.y; }
     else { const uint4 v = *reinterpret_cast<const uint4 *> (iq + 4 * s); r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w; }
     return;
@@ -114,7 +115,28 @@ __device__ __forceinline__ float bcast_lane (float x, int l)
 // the lane below is fetched with the proven z0 as lane 0's old value (no select), the verdict is one compare.
 __device__ __forceinline__ int dc_round (const float *tk, float z0, float B, int lane, int nl, u64 nlmask, float *zt, uint32_t &n_pass)
 {
-  // first guess: the filter in real arithmetic, z' = z + t - z (1 - B), with z ~ z0 over the round
+  // First guess: every sample's step taken from z0 itself, d = RN (t + RN (z0 * B)) - z0.  While z1 stays in z0's binade
+  // and on z0's side of the next point where RN (z * B) leaks one ulp more or less (such points lie 1 / DC_A ulps apart),
+  // RN (z * B) = z - k ulp with z0's k, every z1 is a grid point, and a step adds the same whole number of ulps to any of
+  // them: the prefix sums of d (exact: small multiples of the ulp) ARE the lanes' starts, and the first pass proves all
+  // of them.  Where the round crosses such a point the lanes behind the crossing miss and are refined as below.
+#ifndef DC_LINEAR_GUESS
+  float start;
+  {
+    const float y0 = __fmul_rn (z0, B);
+    float part[kDcPer];
+#pragma unroll
+    for (int q = 0; q < kDcPer; q++) part[q] = __fsub_rn (__fadd_rn (tk[q], y0), z0);
+#pragma unroll
+    for (int w = kDcPer / 2; w >= 1; w >>= 1)
+#pragma unroll
+      for (int q = 0; q < w; q++) part[q] += part[q + w];
+    const float inc = part[0];
+    const float incl = wave_incl_scan_f (inc);
+    start = z0 + (incl - inc);
+  }
+#else
+  // (the filter in real arithmetic, z' = z + t - z (1 - B), with z ~ z0 over the round: what ran before)
   float start;
   {
     float part[kDcPer];
@@ -130,6 +152,7 @@ __device__ __forceinline__ int dc_round (const float *tk, float z0, float B, int
     const float incl = wave_incl_scan_f (inc);
     start = z0 + (incl - inc);
   }
+#endif
   int good = 1;
   // Lanes below `good` are proven and keep their starts; the others take theirs from the end of the last proven lane
   // plus the increments the lanes between them made in this pass -- sums that start at the proven front, so they stay
@@ -213,11 +236,12 @@ __device__ __forceinline__ float dc_chain_batch (const float *t, float *zo, bool
 
 // Magnitudes of four consecutive samples per lane -- samples [b + o, b + o + 4) of a batch whose z1 values lie in zI / zQ
 // (ref: src/convert.c:139-147); `raw` holds their IQ.
-template <int CONV>
+// FULL: the batch holds kDcBatch samples (no bounds to look at)
+template <int CONV, bool FULL>
 __device__ __forceinline__ void dc_magnitudes_go (const DcParams &p, const float *uc8f, const float *zI, const float *zQ,
                                                   const DcRaw<CONV> &raw, long long b, int o, int cnt)
 {
-  if (o >= cnt) return;
+  if (!FULL && o >= cnt) return;
   float fI[4], fQ[4];
   dc_to_float<CONV> (raw, uc8f, fI, fQ);
   const float4 a = *reinterpret_cast<const float4 *> (zI + o);
@@ -233,7 +257,7 @@ __device__ __forceinline__ void dc_magnitudes_go (const DcParams &p, const float
     *reinterpret_cast<float4 *> (p.mag_sq + b + o) = q4;
   }
   uint16_t *dst = p.mag + b + o;
-  if (o + 4 <= cnt) {
+  if (FULL || o + 4 <= cnt) {
     uint32_t *d32 = reinterpret_cast<uint32_t *> (dst);          // p.mag is 4-byte aligned, b and o are even
     d32[0] = m[0] | (m[1] << 16); d32[1] = m[2] | (m[3] << 16);
   } else {
@@ -282,12 +306,22 @@ void dc_chain_kernel (const DcParams p)
   float z = wv == 0 ? d.zIlo : wv == 1 ? d.zIhi : wv == 2 ? d.zQlo : d.zQhi;
   const float A = p.A, B = p.B;
   uint32_t n_guess = 0, n_plain = 0;
-  long long tm_chain = 0, tm_bar = 0, tm_bar_region = 0, tm_total = clock64 ();
+  // (clock reads only while a profile is asked for -- MODES_DC_PROFILE sets `ticks`: each costs the chain wave a scalar memory round trip)
+  const bool prof = p.ticks != nullptr;
+  auto now = [&] () -> long long { return prof ? clock64 () : 0ll; };
+  long long tm_chain = 0, tm_bar = 0, tm_bar_region = 0, tm_total = now ();
 
   DcRaw<CONV> raw[NG];                                                // IQ of the batch to stage next
+  // (whole batches -- all but a stream's last -- take the paths without bounds: a fifth fewer operations for the helpers,
+  // whose issue rate is what the chunk's own samples cost)
   auto fetch = [&] (long long b, DcRaw<CONV> *r) {
+    if (b + kDcBatch <= c1) {
 #pragma unroll
-    for (int k = 0; k < NG; k++) { const int go = hidx + nh * k; if (go < kGoes) dc_load4<CONV> (p.iq, b + 256 * go + 4 * lane, c1, r[k]); }
+      for (int k = 0; k < NG; k++) { const int go = hidx + nh * k; if (go < kGoes) dc_load4<CONV, true> (p.iq, b + 256 * go + 4 * lane, c1, r[k]); }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NG; k++) { const int go = hidx + nh * k; if (go < kGoes) dc_load4<CONV, false> (p.iq, b + 256 * go + 4 * lane, c1, r[k]); }
+    }
   };
   auto stage = [&] (int par) {
 #pragma unroll
@@ -306,11 +340,20 @@ void dc_chain_kernel (const DcParams p)
   auto magnitudes = [&] (int par, long long b, int cnt) {             // of batch b, whose z1 lie in s_buf[par]; its IQ is read again (L2 holds it)
     DcRaw<CONV> rawm[NG];
     fetch (b, rawm);
+    if (cnt == kDcBatch) {
 #pragma unroll
-    for (int k = 0; k < NG; k++) {
-      const int go = hidx + nh * k;
-      if (go >= kGoes) break;
-      dc_magnitudes_go<CONV> (p, s_uc8, s_buf[par][0], s_buf[par][1], rawm[k], b, 256 * go + 4 * lane, cnt);
+      for (int k = 0; k < NG; k++) {
+        const int go = hidx + nh * k;
+        if (go >= kGoes) break;
+        dc_magnitudes_go<CONV, true> (p, s_uc8, s_buf[par][0], s_buf[par][1], rawm[k], b, 256 * go + 4 * lane, cnt);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NG; k++) {
+        const int go = hidx + nh * k;
+        if (go >= kGoes) break;
+        dc_magnitudes_go<CONV, false> (p, s_uc8, s_buf[par][0], s_buf[par][1], rawm[k], b, 256 * go + 4 * lane, cnt);
+      }
     }
   };
   if (helper && d.start < c1) {
@@ -355,28 +398,28 @@ void dc_chain_kernel (const DcParams p)
     if (!helper) {
       const bool closed = (wv & 1) && (wv == 1 ? sIlo == sIhi : sQlo == sQhi);     // a hi chain that has met its lo chain
       if (!closed) {
-        const long long tc = clock64 ();
+        const long long tc = now ();
         float *t = s_buf[pb][wv >> 1];
         z = dc_chain_batch (t, t, !(wv & 1) && keep_z, cnt, z, B, lane, n_guess, n_plain);
         if (lane == 0) {
           s_state[pb ^ 1][wv] = z;
           if (!(wv & 1) && (wv == 0 ? sIlo == sIhi : sQlo == sQhi)) s_state[pb ^ 1][wv + 1] = z;   // the closed hi chain follows
         }
-        tm_chain += clock64 () - tc;
+        tm_chain += now () - tc;
       }
     } else {
-      const long long tc = clock64 ();
+      const long long tc = now ();
       if (prev_ok) magnitudes (pb ^ 1, prev_b, prev_cnt);
       if (b + kDcBatch < c1) {
         stage (pb ^ 1);
         if (b + 2 * kDcBatch < c1) fetch (b + 2 * kDcBatch, raw);
       }
-      tm_chain += clock64 () - tc;
+      tm_chain += now () - tc;
     }
-    const long long tb = clock64 ();
+    const long long tb = now ();
     __syncthreads ();
-    tm_bar += clock64 () - tb;
-    if (region) tm_bar_region += clock64 () - tb;
+    tm_bar += now () - tb;
+    if (region) tm_bar_region += now () - tb;
     if (!helper && (wv & 1)) z = s_state[pb ^ 1][wv];              // (a closed hi chain follows its lo chain)
     prev_ok = keep_z; prev_b = b; prev_cnt = cnt;
   }
@@ -389,7 +432,7 @@ void dc_chain_kernel (const DcParams p)
   if (lane == 0 && wv == 0 && p.ticks) p.ticks[16 * size_t (d.chunk) + 12] = (unsigned long long) tm_bar_region;
   if (lane == 0 && !helper && p.ticks) { unsigned long long *o = p.ticks + 16 * size_t (d.chunk) + 5 + 2 * wv; o[0] = n_guess; o[1] = n_plain; }
   if (lane == 0 && !helper && p.rounds) { atomicAdd (&p.rounds[0], (unsigned long long) n_guess); atomicAdd (&p.rounds[1], (unsigned long long) n_plain);
-    if (wv == 0) { atomicAdd (&p.rounds[2], (unsigned long long) tm_chain); atomicAdd (&p.rounds[3], (unsigned long long) tm_bar); atomicAdd (&p.rounds[4], (unsigned long long) (clock64 () - tm_total)); atomicMax (&p.rounds[5], (unsigned long long) (clock64 () - tm_total)); if (p.ticks) { unsigned long long *o = p.ticks + 16 * size_t (d.chunk); o[0] = (unsigned long long) (clock64 () - tm_total); o[1] = n_guess; o[2] = n_plain; o[3] = (unsigned long long) tm_chain; o[4] = (unsigned long long) tm_bar; } } }
+    if (wv == 0) { atomicAdd (&p.rounds[2], (unsigned long long) tm_chain); atomicAdd (&p.rounds[3], (unsigned long long) tm_bar); atomicAdd (&p.rounds[4], (unsigned long long) (now () - tm_total)); atomicMax (&p.rounds[5], (unsigned long long) (now () - tm_total)); if (p.ticks) { unsigned long long *o = p.ticks + 16 * size_t (d.chunk); o[0] = (unsigned long long) (now () - tm_total); o[1] = n_guess; o[2] = n_plain; o[3] = (unsigned long long) tm_chain; o[4] = (unsigned long long) tm_bar; } } }
 }
 
 // ---- where the filter would be in real arithmetic ---------------------------------------------------------------
