@@ -239,8 +239,10 @@ struct modes_engine {
   DevBuf<float> dc_zc, dc_ckpt;
   DevBuf<long long> dc_closed;
   DevBuf<unsigned long long> dc_ticks;
-  hipEvent_t dc_power_done = nullptr;        // the block powers of a filter_dc run are formed beside the scan
-  bool dc_power_pending = false;
+  hipEvent_t dc_power_done = nullptr, dc_power_go = nullptr;     // the block powers of a filter_dc run are formed behind the scan, beside the ordered pass
+  bool dc_power_pending = false, dc_power_unqueued = false;
+  const float *dc_power_sq = nullptr; uint64_t dc_power_n = 0;
+  hipStream_t power_stream = nullptr;       // lowest priority: the block powers give way to the scan kernels
   hipEvent_t dc_ev[4] = { nullptr, nullptr, nullptr, nullptr };   // around the chain launch / around each repair launch
   float dc_A = 0.0f, dc_B = 1.0f, dc_z[2] = { 0.0f, 0.0f };
   uint64_t dc_lead = 0, dc_warm = 0;
@@ -390,6 +392,7 @@ int fill_scan_params (modes_engine *e, const void *d_iq, size_t nbytes, const ui
 // independent chunks, each warmed up from a bracket that must have closed by the chunk's first sample; a chunk whose
 // bracket is still open -- or whose start state differs from the end state of the chunk before -- is re-run from that
 // exact end state, in order, so the result is the sequential one whatever the warm-up length.
+int queue_dc_power (modes_engine *e, hipStream_t stream);
 int prepare_dc (modes_engine *e, const void *d_iq, size_t nbytes, const uint16_t *d_halo, hipStream_t stream, ScanParams *sp)
 {
   const int bps = bytes_per_sample (e->cfg.input_format);
@@ -613,15 +616,35 @@ int prepare_dc (modes_engine *e, const void *d_iq, size_t nbytes, const uint16_t
     // sample order (ref: src/convert.c:146,153-154) -- formed from the values the chain kernel left, repairs included
     const uint32_t nblocks = uint32_t ((n + e->block_samples - 1) / e->block_samples);
     if ((rc = e->block_power.reserve (nblocks)) != MODES_OK) return rc;
-    // (a bandwidth-bound pass that nothing in the decode reads: on a stream of its own, beside the scan kernel; the host
-    // has waited for the chain above, and the caller's stream waits for this kernel before the run is over)
+    // (a bandwidth-bound pass over 4 bytes per sample that nothing in the decode reads: queued by queue_dc_power () on a
+    // stream of its own BEHIND the scan kernels -- beside them it took their bandwidth -- where it runs under the ordered
+    // pass, the emit and the read-back, which are bound by latency; the caller's stream waits for it before the run is over)
     if (!e->copy_stream) HIP_TRY (hipStreamCreateWithFlags (&e->copy_stream, hipStreamNonBlocking));
     if (!e->dc_power_done) HIP_TRY (hipEventCreateWithFlags (&e->dc_power_done, hipEventDisableTiming));
-    HIP_TRY (launch_dc_block_power (q.mag_sq + back, n, e->block_samples, nblocks, e->block_power.p, e->copy_stream));
-    HIP_TRY (hipEventRecord (e->dc_power_done, e->copy_stream));
-    e->dc_power_pending = true;
+    if (!e->dc_power_go) HIP_TRY (hipEventCreateWithFlags (&e->dc_power_go, hipEventDisableTiming));
+    e->dc_power_sq = q.mag_sq + back; e->dc_power_n = n;
+    e->dc_power_unqueued = true;
     e->nblocks_power = nblocks;
+    if (getenv ("MODES_DC_POWER_EARLY")) { if ((rc = queue_dc_power (e, stream)) != MODES_OK) return rc; }     // (experiments: beside the scan kernels)
   }
+  return MODES_OK;
+}
+
+// The block powers of a filter_dc run (prepare_dc): behind everything queued on `stream` so far.
+int queue_dc_power (modes_engine *e, hipStream_t stream)
+{
+  if (!e->dc_power_unqueued) return MODES_OK;
+  e->dc_power_unqueued = false;
+  if (!e->power_stream) {
+    int least = 0, greatest = 0;
+    HIP_TRY (hipDeviceGetStreamPriorityRange (&least, &greatest));
+    HIP_TRY (hipStreamCreateWithPriority (&e->power_stream, hipStreamNonBlocking, getenv ("MODES_DC_POWER_PRIO") ? atoi (getenv ("MODES_DC_POWER_PRIO")) : least));
+  }
+  HIP_TRY (hipEventRecord (e->dc_power_go, stream));
+  HIP_TRY (hipStreamWaitEvent (e->power_stream, e->dc_power_go, 0));
+  HIP_TRY (launch_dc_block_power (e->dc_power_sq, e->dc_power_n, e->block_samples, e->nblocks_power, e->block_power.p, e->power_stream));
+  HIP_TRY (hipEventRecord (e->dc_power_done, e->power_stream));
+  e->dc_power_pending = true;
   return MODES_OK;
 }
 
@@ -977,6 +1000,7 @@ int scan_and_accept_in_ranges (modes_engine *e, ScanParams &sp, uint64_t first_s
     modes_engine *e; hipStream_t s;
     ~Drain () {
       (void) hipStreamSynchronize (e->post_stream); (void) hipStreamSynchronize (e->emit_stream); (void) hipStreamSynchronize (e->copy_stream);
+      if (e->power_stream) (void) hipStreamSynchronize (e->power_stream);
       (void) hipStreamSynchronize (s);
     }
   } drain = { e, stream };
@@ -986,6 +1010,7 @@ int scan_and_accept_in_ranges (modes_engine *e, ScanParams &sp, uint64_t first_s
   // with the rounds of the ranges before
   for (uint32_t r = 0; r < nranges; r++) HIP_TRY (queue_scan (r));
   HIP_TRY (launch_tail (sp, sp.nsamples, e->tail.p + e->tail_half * ((e->ov + 7u) & ~7u), stream));   // what a following shard needs as d_halo
+  { const int prc = queue_dc_power (e, stream); if (prc != MODES_OK) return prc; }
   e->scan_launches++;
   const bool timing = getenv ("MODES_TIMING") != nullptr;              // the host's way through the ranges on stderr
   e->marking = timing;
@@ -1097,6 +1122,8 @@ void modes_engine_destroy (modes_engine *e)
   e->dc_lin.release (); e->dc_ticks.release (); e->dc_zc.release (); e->dc_ckpt.release (); e->dc_closed.release ();
   for (hipEvent_t ev : e->dc_ev) if (ev) (void) hipEventDestroy (ev);
   if (e->dc_power_done) (void) hipEventDestroy (e->dc_power_done);
+  if (e->dc_power_go) (void) hipEventDestroy (e->dc_power_go);
+  if (e->power_stream) (void) hipStreamDestroy (e->power_stream);
   for (hipEvent_t ev : e->round_ev) if (ev) (void) hipEventDestroy (ev);
   if (e->fin_ev) (void) hipEventDestroy (e->fin_ev);
   e->dc_mag.release (); e->dc_sq.release (); e->dc_desc.release (); e->dc_zs.release (); e->dc_ze.release (); e->dc_unm.release ();
@@ -1232,6 +1259,7 @@ static int scan_and_decode (modes_engine *e, ScanParams &sp, uint64_t first_samp
   e->scan_launches++;
   HIP_TRY (hipEventRecord (e->ev[1], stream));
   HIP_TRY (launch_tail (sp, sp.nsamples, e->tail.p + e->tail_half * ((e->ov + 7u) & ~7u), stream));   // what a following shard needs as d_halo
+  if ((rc = queue_dc_power (e, stream)) != MODES_OK) return rc;
 
   if (device_accept) {
     rc = run_accept_on_device (e, sp, first_sample, stream);
@@ -2035,6 +2063,7 @@ int modes_engine_run_device (modes_engine *e, const void *d_iq, size_t nbytes, u
   if (!e || (!d_iq && nbytes)) return fail (MODES_E_ARG, "null argument");
   if (e->mode == 8000) return run_8000 (e, d_iq, nbytes, first_sample, d_halo, static_cast<hipStream_t> (stream_v));
   int rc = run_device_inner (e, d_iq, nbytes, first_sample, d_halo, stream_v);
+  if (e->dc_power_unqueued) { const int prc = queue_dc_power (e, static_cast<hipStream_t> (stream_v)); if (rc == MODES_OK) rc = prc; }   // (a path that queued no scan of its own)
   if (e->dc_power_pending) {               // the block powers of a filter_dc run: formed beside the scan, done when the caller's stream is
     e->dc_power_pending = false;
     HIP_TRY (hipStreamWaitEvent (static_cast<hipStream_t> (stream_v), e->dc_power_done, 0));
