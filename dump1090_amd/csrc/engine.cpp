@@ -235,7 +235,7 @@ struct modes_engine {
   DevBuf<DcChunk> dc_desc;
   DevBuf<float> dc_zs, dc_ze;
   DevBuf<uint32_t> dc_unm;
-  DevBuf<double> dc_lin;
+  DevBuf<double> dc_lin, dc_wtab;
   DevBuf<float> dc_zc, dc_ckpt;
   DevBuf<long long> dc_closed;
   DevBuf<unsigned long long> dc_ticks;
@@ -443,7 +443,14 @@ int prepare_dc (modes_engine *e, const void *d_iq, size_t nbytes, const uint16_t
   std::vector<double> est (2 * (nseg + 1)), half (2 * (nseg + 1));     // value and half-width of the bracket, per channel
   {
     if ((rc = e->dc_lin.reserve (2 * nseg)) != MODES_OK) return rc;
-    HIP_TRY (launch_dc_linear (e->conv, static_cast<const uint8_t *> (d_iq) - (back + lead_eff) * bps, total, double (e->dc_A), double (e->dc_B),
+    if (!e->dc_wtab.p) {                                               // B^(1023 - j) for the kernel's Horner steps, and B^1024
+      if ((rc = e->dc_wtab.reserve (1025)) != MODES_OK) return rc;
+      std::vector<double> w (1025);
+      for (int j = 0; j < 1024; j++) w[j] = std::pow (double (e->dc_B), double (1023 - j));
+      w[1024] = std::pow (double (e->dc_B), 1024.0);
+      HIP_TRY (hipMemcpy (e->dc_wtab.p, w.data (), w.size () * sizeof (double), hipMemcpyHostToDevice));
+    }
+    HIP_TRY (launch_dc_linear (e->conv, static_cast<const uint8_t *> (d_iq) - (back + lead_eff) * bps, total, double (e->dc_A), e->dc_wtab.p,
                                e->dc_lin.p, stream));
     std::vector<double> S (2 * nseg);
     HIP_TRY (hipMemcpyAsync (S.data (), e->dc_lin.p, 2 * nseg * sizeof (double), hipMemcpyDeviceToHost, stream));
@@ -1119,7 +1126,7 @@ void modes_engine_destroy (modes_engine *e)
   e->block_power.release (); e->noise_level.release ();
   e->raw_len.release (); e->raw_off.release (); e->raw_cs.release (); e->raw_cv.release (); e->raw_co.release (); e->raw_text.release ();
   if (e->pin_text) (void) hipHostFree (e->pin_text);
-  e->dc_lin.release (); e->dc_ticks.release (); e->dc_zc.release (); e->dc_ckpt.release (); e->dc_closed.release ();
+  e->dc_lin.release (); e->dc_wtab.release (); e->dc_ticks.release (); e->dc_zc.release (); e->dc_ckpt.release (); e->dc_closed.release ();
   for (hipEvent_t ev : e->dc_ev) if (ev) (void) hipEventDestroy (ev);
   if (e->dc_power_done) (void) hipEventDestroy (e->dc_power_done);
   if (e->dc_power_go) (void) hipEventDestroy (e->dc_power_go);

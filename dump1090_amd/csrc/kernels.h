@@ -49,7 +49,7 @@ hipError_t launch_fields (const void *msgs, uint32_t n, struct ::modes_fields *o
 // kernels_dc.hip
 hipError_t launch_dc_chain (int conv, const DcParams &p, uint32_t ndesc, hipStream_t stream);
 hipError_t launch_dc_block_power (const float *sq, uint64_t n, uint32_t block_samples, uint32_t nblocks, double *mean_power, hipStream_t stream);
-hipError_t launch_dc_linear (int conv, const uint8_t *iq, uint64_t n, double A, double B, double *out, hipStream_t stream);
+hipError_t launch_dc_linear (int conv, const uint8_t *iq, uint64_t n, double A, const double *wtab /* [1025]: B^(1023 - j), B^1024 */, double *out, hipStream_t stream);
 hipError_t launch_accept2400 (const AcceptParams &p, hipStream_t stream);
 hipError_t launch_snapshots (const uint32_t *delta, const uint32_t *blk_wrote, uint32_t nblocks, const uint32_t *cache_in, uint32_t *chunk_last,
                              uint32_t *chunk_entry, uint32_t *snap_in, uint32_t *cache_out, uint32_t *dirty, const uint32_t *changed, uint32_t *marked,

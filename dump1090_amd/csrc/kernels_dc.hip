@@ -442,7 +442,7 @@ void dc_chain_kernel (const DcParams p)
 // starting brackets are built from.  One workgroup per segment of kDcSeg samples.
 template <int CONV>
 __global__ __launch_bounds__ (256)
-void dc_linear_kernel (const uint8_t *iq, long long n, double A, double B, double *out /* [segments][2] */)
+void dc_linear_kernel (const uint8_t *iq, long long n, double A, const double *wtab /* [1025]: B^(1023 - j), B^1024 */, double *out /* [segments][2] */)
 {
   __shared__ float s_uc8[256];
   __shared__ double s_part[2][4];
@@ -452,10 +452,11 @@ void dc_linear_kernel (const uint8_t *iq, long long n, double A, double B, doubl
   const long long s0 = (long long) blockIdx.x * kDcSeg;
   const long long s1 = min (s0 + (long long) kDcSeg, n);
   // sample 1024 g + 4 tid + k of the segment carries the weight B^(kDcSeg - 1 - that): Horner over g with B^1024
+  // (the weights come from a table the host made once: five pow () per thread were a third of this kernel)
   double w[4];
 #pragma unroll
-  for (int k = 0; k < 4; k++) w[k] = pow (B, double (1023 - 4 * tid - k));
-  const double B1024 = pow (B, 1024.0);
+  for (int k = 0; k < 4; k++) w[k] = wtab[4 * tid + k];
+  const double B1024 = wtab[1024];
   double aI = 0.0, aQ = 0.0;
   for (int g = 0; g < kDcSeg / 1024; g++) {
     DcRaw<CONV> raw;
@@ -538,14 +539,14 @@ hipError_t launch_dc_block_power (const float *sq, uint64_t n, uint32_t block_sa
   return hipGetLastError ();
 }
 
-hipError_t launch_dc_linear (int conv, const uint8_t *iq, uint64_t n, double A, double B, double *out, hipStream_t stream)
+hipError_t launch_dc_linear (int conv, const uint8_t *iq, uint64_t n, double A, const double *wtab, double *out, hipStream_t stream)
 {
   if (n == 0) return hipSuccess;
   const dim3 grid ((unsigned) ((n + kDcSeg - 1) / kDcSeg)), block (256);
   switch (conv) {
-    case kConvUc8Generic:     hipLaunchKernelGGL (dc_linear_kernel<kConvUc8Generic>, grid, block, 0, stream, iq, (long long) n, A, B, out); break;
-    case kConvSc16Generic:    hipLaunchKernelGGL (dc_linear_kernel<kConvSc16Generic>, grid, block, 0, stream, iq, (long long) n, A, B, out); break;
-    case kConvSc16Q11Generic: hipLaunchKernelGGL (dc_linear_kernel<kConvSc16Q11Generic>, grid, block, 0, stream, iq, (long long) n, A, B, out); break;
+    case kConvUc8Generic:     hipLaunchKernelGGL (dc_linear_kernel<kConvUc8Generic>, grid, block, 0, stream, iq, (long long) n, A, wtab, out); break;
+    case kConvSc16Generic:    hipLaunchKernelGGL (dc_linear_kernel<kConvSc16Generic>, grid, block, 0, stream, iq, (long long) n, A, wtab, out); break;
+    case kConvSc16Q11Generic: hipLaunchKernelGGL (dc_linear_kernel<kConvSc16Q11Generic>, grid, block, 0, stream, iq, (long long) n, A, wtab, out); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError ();
