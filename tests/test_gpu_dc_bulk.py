@@ -174,3 +174,40 @@ def test_mode_ac_behind_the_dc_converter():
         for k in ("valid_preamble", "demod_modeac", "demodulated", "CRC_good"):
             assert gst[k] == est[k], k
         assert np.array_equal(e.block_power(), o.last_block_power)
+
+
+def _quiet_uc8(n, seed, sigma, offs, bursts=True):
+    """Noise of `sigma` LSB around a constant offset (where z1 settles on a point at which RN (z * B) changes its leak and
+    crosses it every few samples: the rounds' first guess misses, lanes are proven a few at a time), with a few bursts."""
+    rng = np.random.default_rng(seed)
+    v = 127.5 + np.array(offs)[None, :] + sigma * rng.standard_normal((n, 2))
+    if bursts:
+        for p in rng.integers(0, n - 300, size=max(1, n // 400000)):
+            v[p:p + 240:2] += 60.0
+    return np.clip(np.rint(v), 0, 255).astype(np.uint8).reshape(-1)
+
+
+@pytest.mark.parametrize("sigma,offs", [(1.5, (1.4, -2.17)), (0.7, (1.4, -2.17)), (0.3, (-3.2, 0.6)), (0.0, (0.5, 0.5))])
+def test_noise_on_a_constant_offset(sigma, offs):
+    """The regime the exact first guess of a round does not cover: every magnitude, the final filter state
+    and the block powers must still be the sequential ones, whatever number of passes and partial rounds it takes."""
+    n = 3_000_000
+    iq = _quiet_uc8(n, 41, sigma, offs)
+    e = check_run(iq, "uc8", 2400000, expect_min_msgs=0)
+    assert e.dc_info()["chunks"] >= 32
+    o = orc.Oracle(2400000, fix_bits=1, measure_noise=True)
+    o.run_stream(iq, orc.INPUT_UC8, 2400, filter_dc=True, compute_power=True)
+    est, gst = o.stats(), e.power_stats()
+    assert gst["noise_valid"] == 1 and gst["noise_power_count"] == est["noise_power_count"]
+    np.testing.assert_allclose(gst["noise_power_sum"], est["noise_power_sum"], rtol=1e-9)     # (a sum of per-block doubles: the blocks' values are bit-equal)
+
+
+def test_silence_then_signal_sc16():
+    """sc16 with stretches of exact zeros (z1 decays through the binades) between noise: ragged chunk ends included."""
+    rng = np.random.default_rng(43)
+    n = 2_500_003
+    v = np.zeros((n, 2))
+    for a in range(0, n, 500000):
+        v[a:a + 230000] = 40.0 * rng.standard_normal((min(230000, n - a), 2)) + np.array([310.0, -120.0])
+    iq = np.clip(np.rint(v), -32768, 32767).astype(np.int16).reshape(-1)
+    check_run(iq, "sc16", 2400000, expect_min_msgs=0)
