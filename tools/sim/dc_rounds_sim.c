@@ -1,4 +1,4 @@
-// chain rounds on noise-only uc8 input: passes per round for several refinement rules
+// chain rounds on noise-only input (-DFMT16=1: sc16 samples, -DFMT16=0: uc8): passes per round for several refinement rules; gcc -O2 -ffp-contract=off -DFMT16=1 dc_rounds_sim.c -lm; ./a.out <sigma in uc8 LSB> <offset in uc8 LSB> <variant 0..2>
 #include <stdio.h>
 #include <stdlib.h>
 #include <math.h>
@@ -20,11 +20,11 @@ int main (int argc, char **argv)
   const long warm = 3000000;
   float z = (float) (dc / 127.5);
   // settle sequentially
-  for (long n = 0; n < warm; n++) { int b = (int) lrint (127.5 + dc + sigma * nrand ()); if (b < 0) b = 0; if (b > 255) b = 255; const float f = (float) ((b - 127.5) / 127.5); const float t = f * A; z = t + z * B; }
+  for (long n = 0; n < warm; n++) { const float f = FMT16 ? (float) (int) lrint ((dc + sigma * nrand ()) * 257.0) * (1.0f / 32768.0f) : (float) ((fmin (255, fmax (0, lrint (127.5 + dc + sigma * nrand ()))) - 127.5) / 127.5); const float t = f * A; z = t + z * B; }
   long passes = 0, nrounds = 0, partial = 0;
   float t[NL * PER];
   for (int r = 0; r < rounds; r++) {
-    for (int i = 0; i < NL * PER; i++) { int b = (int) lrint (127.5 + dc + sigma * nrand ()); if (b < 0) b = 0; if (b > 255) b = 255; const float f = (float) ((b - 127.5) / 127.5); t[i] = f * A; }
+    for (int i = 0; i < NL * PER; i++) { const float f = FMT16 ? (float) (int) lrint ((dc + sigma * nrand ()) * 257.0) * (1.0f / 32768.0f) : (float) ((fmin (255, fmax (0, lrint (127.5 + dc + sigma * nrand ()))) - 127.5) / 127.5); t[i] = f * A; }
     int base = 0;
     while (base < NL * PER) {
       const int nl = (NL * PER - base) / PER;
