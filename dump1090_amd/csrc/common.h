@@ -168,7 +168,6 @@ struct AcceptParams {
   const uint32_t *cache_in;
   uint32_t       *blk_wrote;
   int32_t         first_round;
-  int32_t         alone;         // the pass has the GPU to itself (a single range behind its scan): four blocks per workgroup
 };
 
 // One completed match window of demod_8000 (ref: src/demod-8000.c:331-420)

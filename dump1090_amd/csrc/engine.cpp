@@ -787,8 +787,7 @@ int pass_queue_round (modes_engine *e, const ScanParams &sp, PassState &ps)
 }
 
 // prev: the range before this one, whose exit cache is on the device (null: the range starts from e->cache)
-int pass_begin (modes_engine *e, const ScanParams &sp, hipStream_t stream, const RangeView &rg, uint32_t par, const PassState *prev, PassState &ps,
-                bool alone = false)      // alone: no scan runs beside this pass (AcceptParams::alone)
+int pass_begin (modes_engine *e, const ScanParams &sp, hipStream_t stream, const RangeView &rg, uint32_t par, const PassState *prev, PassState &ps)
 {
   const uint32_t B = e->block_samples;
   ps.rg = rg; ps.stream = stream; ps.par = par & 1; ps.queued = ps.rounds = 0;
@@ -816,7 +815,7 @@ int pass_begin (modes_engine *e, const ScanParams &sp, hipStream_t stream, const
   ap.snap_in = e->snap_in.p; ap.delta = e->delta.p; ap.acc_counts = e->acc_counts.p; ap.blk_stats = e->blk_stats.p;
   ap.vp_bitmap = e->mode == 2400 ? e->vp_bitmap.p : nullptr;
   ap.mode = e->mode;
-  ap.cache_in = d_cache_in; ap.blk_wrote = e->blk_wrote.p; ap.first_round = 1; ap.alone = alone;
+  ap.cache_in = d_cache_in; ap.blk_wrote = e->blk_wrote.p; ap.first_round = 1;
   if (!e->round_ev[0]) for (hipEvent_t &ev : e->round_ev) HIP_TRY (hipEventCreateWithFlags (&ev, hipEventDisableTiming));
   return pass_queue_round (e, sp, ps);
 }
@@ -935,7 +934,7 @@ int pass_finish (modes_engine *e, const ScanParams &sp, uint64_t first_sample, P
 int accept_range (modes_engine *e, const ScanParams &sp, uint64_t first_sample, hipStream_t stream, const RangeView &rg, bool last)
 {
   PassState ps;
-  int rc = pass_begin (e, sp, stream, rg, 0, nullptr, ps, true);
+  int rc = pass_begin (e, sp, stream, rg, 0, nullptr, ps);
   if (rc == MODES_OK) rc = pass_settle (e, sp, ps);
   if (rc == MODES_OK) rc = pass_finish (e, sp, first_sample, ps, last, stream, nullptr, nullptr);
   return rc;

@@ -790,16 +790,14 @@ struct AcceptLds {
 __device__ __forceinline__ uint32_t rdlane (uint32_t v, int l) { return uint32_t (__builtin_amdgcn_readlane (int (v), l)); }
 
 // One wave per workgroup and 5 KiB of LDS: the pass of one range of blocks runs while the next range is scanned, and a
-// workgroup this small finds room on a CU the scan kernel has filled.  WAVES = 4 (AcceptParams::alone): a pass with the
-// GPU to itself -- a quiet recording's 16 384 one-wave workgroups took 49 us just to be dispatched.  Waves never meet:
-// everything below is wave-synchronous.
-template <int MODE, int WAVES>
-__global__ __launch_bounds__ (64 * WAVES)
+// workgroup this small finds room on a CU the scan kernel has filled.
+template <int MODE>
+__global__ __launch_bounds__ (64)
 void accept_kernel (const AcceptParams p)
 {
-  __shared__ AcceptLds lds[WAVES];
-  const int lane = threadIdx.x & 63, wv = WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane (int (threadIdx.x >> 6));
-  const uint32_t blk = p.blk_begin + blockIdx.x * WAVES + wv;
+  __shared__ AcceptLds lds[1];
+  const int lane = threadIdx.x & 63, wv = 0;
+  const uint32_t blk = p.blk_begin + blockIdx.x;
   if (blk >= (p.blk_end ? p.blk_end : p.nblocks)) return;
   if (p.dirty && !p.dirty[blk]) return;                      // same entry cache as in the round before: same results
   __builtin_amdgcn_s_setprio (3);                            // the pass is latency bound and often shares the GPU with a scan
@@ -1649,13 +1647,8 @@ hipError_t launch_accept2400 (const AcceptParams &p, hipStream_t stream)
 {
   const uint32_t nb = (p.blk_end ? p.blk_end : p.nblocks) - p.blk_begin;
   if (p.nblocks == 0 || nb == 0) return hipSuccess;
-  if (p.alone) {
-    if (p.mode == 2000) hipLaunchKernelGGL ((accept_kernel<2000, 4>), dim3 ((nb + 3) / 4), dim3 (256), 0, stream, p);
-    else                hipLaunchKernelGGL ((accept_kernel<2400, 4>), dim3 ((nb + 3) / 4), dim3 (256), 0, stream, p);
-  } else {
-    if (p.mode == 2000) hipLaunchKernelGGL ((accept_kernel<2000, 1>), dim3 (nb), dim3 (64), 0, stream, p);
-    else                hipLaunchKernelGGL ((accept_kernel<2400, 1>), dim3 (nb), dim3 (64), 0, stream, p);
-  }
+  if (p.mode == 2000) hipLaunchKernelGGL (accept_kernel<2000>, dim3 (nb), dim3 (64), 0, stream, p);
+  else                hipLaunchKernelGGL (accept_kernel<2400>, dim3 (nb), dim3 (64), 0, stream, p);
   return hipGetLastError ();
 }
 
